@@ -1,0 +1,44 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+REF_DIR = "/root/reference"  # exists only in the build container, never on the GPU box
+C0_MATRIX = os.path.join(REF_DIR, "matrix_poisson_P1_14401")
+C0_RHS = os.path.join(REF_DIR, "matrix_poisson_P1rhs_14401")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long CPU test (still part of the default CPU suite unless deselected)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    with open(os.path.join(ROOT, "tests", "golden", "appendix_a.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def have_c0():
+    return os.path.exists(C0_MATRIX) and os.path.exists(C0_RHS)
+
+
+def rel_close(a, b, rtol):
+    a = np.asarray(a, dtype=float)
+    b = np.asarray(b, dtype=float)
+    return np.all(np.abs(a - b) <= rtol * np.abs(b))
+
+
+def hist_tolerance(ref_hist):
+    """Per-iteration tolerance of SURVEY.md §8(d): 1e-6 relative while r_k >= 1e-6 r_0,
+    1e-3 relative below that."""
+    ref_hist = np.asarray(ref_hist, dtype=float)
+    r0 = ref_hist[0]
+    return np.where(ref_hist >= 1e-6 * r0, 1e-6, 1e-3)
