@@ -1,0 +1,168 @@
+/*
+ * sparsh_amg.h -- C ABI of libsparsh_amg.so: the MI355X-native AMG solve phase.
+ *
+ * The reference (cmgcds/SParSH-AMG) has no C ABI or plugin interface; its boundary is the
+ * C++ source-level API of include/AMG.hpp (17 free functions on sp_matrix_mg, statically
+ * linked).  That C++ surface is re-exported by this library through include/AMG.hpp,
+ * include/AMG_matrix.hpp and include/AMG_cpu_matrix.hpp of THIS repo (same names, same
+ * signatures), so the reference's main.cpp links against libsparsh_amg.so unchanged.
+ *
+ * This header is the plain-C mirror a non-C++ host (ctypes, cgo, JNI ...) binds: plain
+ * pointers and sizes, int return codes, no globals.  Each entry cites the reference
+ * interface it stands for (file:line relative to the reference tree).
+ *
+ * Conventions: 0-based CSR, int32 indices, fp64 values, caller-owned host buffers unless a
+ * name ends in _dev (device pointers in HBM of the handle's GPU).  Return 0 on success,
+ * negative SPARSH_E* otherwise; sparsh_last_error() gives the text.
+ */
+#ifndef SPARSH_AMG_H_
+#define SPARSH_AMG_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPARSH_OK 0
+#define SPARSH_EINVAL -1    /* bad argument */
+#define SPARSH_ENODEV -2    /* no HIP device / HIP runtime error */
+#define SPARSH_ESTATE -3    /* call order violated (e.g. solve before setup) */
+#define SPARSH_ENUMERIC -4  /* singular coarse matrix, NaN residual */
+#define SPARSH_ENOCONV -5   /* iteration cap reached before ||r|| <= tol (x still returned) */
+#define SPARSH_ECOMM -6     /* RCCL failure */
+
+/* Solver selection: which reference entry point's arithmetic is followed. */
+#define SPARSH_AMG 0    /* AMG_Solver_CPU_baseline / _CPU_GPU_MI / _CPU_GPU_CI  (src/AMG_main_solvers.cpp:14-26,240-268) */
+#define SPARSH_CG 1     /* Solver_CG_1 / Solver_CG_2        (src/AMG_main_solvers.cpp:47-103, .cu:35-139)  */
+#define SPARSH_PCG 2    /* Solver_PCG_1..4                  (src/AMG_main_solvers.cpp:107-167, .cu:269-413) */
+#define SPARSH_BICG 3   /* Solver_BiCG_1                    (src/AMG_main_solvers.cpp:271-355) */
+#define SPARSH_PBICG 4  /* Solver_PBiCG_1..4                (src/AMG_main_solvers.cpp:358-458) */
+
+/* Runtime form of the compile-time macros of the reference's include/AMG.hpp:15-27.
+ * sparsh_default_params() fills the reference values; the env variables in brackets
+ * override them inside sparsh_default_params(). */
+typedef struct sparsh_params {
+    double omega;       /* omega = 0.66667 (not 2/3)                          [SPARSH_OMEGA]   */
+    double tol;         /* tol1 = 1e-8, absolute ||b-Ax||_2                   [SPARSH_TOL]     */
+    int sweeps;         /* Jacobi sweeps per smoothing step. CPU path of the reference does
+                           smooth_iter+1 = 7 (src/AMG_smoothers.cpp:59-60); its GPU path 6. [SPARSH_NU] */
+    int max_levels;     /* level1 = 6                                          [SPARSH_LEVELS]  */
+    int limit_upper;    /* limit_upper = 4000                                                  */
+    int limit_lower;    /* limit_lower = 2000                                                  */
+    int coarsening;     /* 0 = HEM pairwise aggregation (default, src/AMG_phases.cpp:60),
+                           1 = Beck (src/AMG_phases.cpp:63)                    [SPARSH_COARSENING=hem|beck] */
+    int max_iter;       /* guard the reference lacks: cap on cycles/iterations [SPARSH_MAXIT]   */
+    int coarse_limit;   /* largest coarsest level solved directly on the device (explicit
+                           inverse, one GEMV per V-cycle).  If max_levels leaves a coarsest level
+                           above it, coarsening continues past max_levels (documented deviation
+                           from the reference, which hands any size to PARDISO).  [SPARSH_COARSE_LIMIT] */
+    int host_threads;   /* OpenMP threads for the host setup (0 = all)        [SPARSH_THREADS] */
+    int device;         /* HIP device ordinal (-1 = current / LOCAL_RANK)                     */
+    int print_setup;    /* print_setup_phase_details = 1                       [SPARSH_PRINT]   */
+    int print_solve;    /* print_solve_phase_details = 1                       [SPARSH_PRINT]   */
+    int check_every;    /* Krylov/AMG loops read the residual norm back every k iterations
+                           (1 = reference behaviour: every iteration)                          */
+    int use_graph;      /* capture one V-cycle into a hipGraph and replay it   [SPARSH_GRAPH]   */
+} sparsh_params;
+
+typedef struct sparsh_handle_s *sparsh_handle;
+
+const char *sparsh_last_error(void);
+int sparsh_version(void);
+int sparsh_device_count(void);
+
+void sparsh_default_params(sparsh_params *p);
+
+/* sp_matrix_mg + sp_matrix_fill + sp_matrix_fill_diagonal (include/AMG_cpu_matrix.hpp:12-51,
+ * src/AMG_cpu_matrix.cpp:17-51): register a host CSR.  The arrays are aliased, not copied
+ * (as AMG_solver::Av[0] aliases the caller's matrix, src/AMG_phases.cpp:40) and must
+ * outlive the handle.  Columns must be sorted within each row. */
+int sparsh_create_csr(int nrow, int ncol, const int *rowptr, const int *colindex, const double *val, sparsh_handle *out);
+void sparsh_destroy(sparsh_handle h);
+
+/* AMG_solver::AMG_solver_setup_jacobi (src/AMG_phases.cpp:35-90) followed by what
+ * AMG_GPU1_solver::GPU_Allocations does (src/AMG_gpu_phases_2.cu:13-94): build the hierarchy
+ * on the host, factor the coarsest level, upload everything to HBM (resident). */
+int sparsh_setup(sparsh_handle h, const sparsh_params *p);
+
+/* Host half of sparsh_setup only (coarsening, Galerkin products, coarse factorisation); needs
+ * no GPU.  Enables the inspection calls below; solvers still require sparsh_setup. */
+int sparsh_setup_host(sparsh_handle h, const sparsh_params *p);
+
+/* hierarchy inspection (tests; "Level k:\t nrow" lines of src/AMG_phases.cpp:55-58) */
+int sparsh_num_levels(sparsh_handle h);
+int sparsh_level_info(sparsh_handle h, int level, int *nrow, int *nnz, int *p_ncol, int *p_nnz);
+/* which: 0 = A_level, 1 = P_level (level < last).  Buffers sized from sparsh_level_info. */
+int sparsh_level_csr(sparsh_handle h, int level, int which, int *rowptr, int *colindex, double *val);
+/* explicit inverse of the coarsest operator, row-major nL x nL (what the device GEMV applies in
+ * place of Direct_Solver_Pardiso_solve); available after sparsh_setup_host */
+int sparsh_coarse_inverse(sparsh_handle h, double *inv);
+double sparsh_setup_seconds(sparsh_handle h);
+
+/* AMG_solver::AMG_solve_jacobi(b, x, iterations) (src/AMG_phases.cpp:151-230) ==
+ * AMG_GPU1_solver::helper (src/AMG_gpu_phases_2.cu:242-263): host b/x, V-cycles on the device.
+ * iterations > 0: exactly that many cycles; -1: until ||Ax-b|| <= tol.
+ * hist[k] = residual after cycle k+1 (the value the reference prints). */
+int sparsh_vcycle(sparsh_handle h, const double *b, double *x, int iterations, double *hist, int hist_cap, int *ncycles);
+
+/* The 17 solver entry points of include/AMG.hpp:40-85 reduce to five methods (SPARSH_*).
+ * x: initial guess in, solution out.  hist[k] = residual the reference prints at step k. */
+int sparsh_solve(sparsh_handle h, int method, const double *b, double *x, double *hist, int hist_cap, int *iters);
+
+/* Same with b/x already in HBM (AMG_GPU1_solver::AMG_Solve / Solver_PCG_4 inner loop,
+ * src/AMG_gpu_phases_2.cu:96-240, src/AMG_main_solvers.cu:269-413).  max_iters bounds the
+ * loop (<=0: params.max_iter); *seconds returns the loop time measured with HIP events on the
+ * engine's stream (NULL to skip). */
+int sparsh_solve_dev(sparsh_handle h, int method, const double *b_dev, double *x_dev, int max_iters, double *hist, int hist_cap, int *iters, double *seconds);
+
+/* Stepwise form of the CG / AMG-PCG loop: init = everything before the reference's while loop
+ * (src/AMG_main_solvers.cpp:124-133), step = nsteps passes of the loop body (:136-159), stopping
+ * early only when ||r|| <= tol.  Lets a caller time exactly k iterations.  *residual = last
+ * ||r|| read back; history = residual after each iteration so far. */
+int sparsh_krylov_init_dev(sparsh_handle h, int method, const double *b_dev, double *x_dev);
+int sparsh_krylov_step_dev(sparsh_handle h, int nsteps, int *done, double *residual);
+int sparsh_krylov_history(sparsh_handle h, double *hist, int hist_cap, int *iters);
+
+/* ---- operator-level entry points (kernel parity tests, roofline measurement) ----
+ * Host vectors in/out; each runs exactly one device operator of the given level.
+ *   spmv      : y = A_l x                      mkl_sparse_d_mv / cusparseDcsrmv (src/AMG_gpu_phase_utilities.cu:143)
+ *   jacobi    : sweeps x { x += omega (b - A_l x)/d }   parallel::jacobi_smoother (src/AMG_smoothers.cpp:53-76)
+ *   residual  : r = b - A_l x                  parallel::store_residual (src/AMG_cycle_utilities.cpp:115-123)
+ *   resnorm   : ||A_l x - b||_2                parallel::residual (src/AMG_cycle_utilities.cpp:83-94)
+ *   restrict  : b_{l+1} = P_l^T r              parallel::transfer_residual (src/AMG_cycle_utilities.cpp:97-104)
+ *   prolong   : x_l += P_l x_{l+1}             parallel::transfer_solution (src/AMG_cycle_utilities.cpp:107-112)
+ *   coarse    : x_L = A_L^{-1} b_L             Direct_Solver_Pardiso_solve (src/AMG_coarse_level_solver.cpp:64-76)
+ *   dot/nrm2/axpby : cublasDdot / cublasDnrm2 / daxpby kernel (src/AMG_main_solvers.cu:17-24)
+ */
+int sparsh_op_spmv(sparsh_handle h, int level, const double *x, double *y);
+int sparsh_op_jacobi(sparsh_handle h, int level, const double *b, double *x, int sweeps, int x_is_zero);
+int sparsh_op_residual(sparsh_handle h, int level, const double *b, const double *x, double *r);
+int sparsh_op_resnorm(sparsh_handle h, int level, const double *b, const double *x, double *nrm);
+int sparsh_op_restrict(sparsh_handle h, int level, const double *r, double *bc);
+int sparsh_op_prolong(sparsh_handle h, int level, const double *xc, double *xf);
+int sparsh_op_coarse(sparsh_handle h, const double *b, double *x);
+int sparsh_op_dot(sparsh_handle h, int n, const double *x, const double *y, double *out);
+int sparsh_op_nrm2(sparsh_handle h, int n, const double *x, double *out);
+int sparsh_op_axpby(sparsh_handle h, int n, double a, const double *x, double bcoef, double *y);
+
+/* Time `reps` back-to-back launches of one operator on resident device data with HIP events
+ * on the engine's stream; returns average seconds per launch.  op: 0 spmv, 1 fused jacobi
+ * sweep, 2 residual, 3 restrict, 4 prolong, 5 coarse GEMV, 6 dot, 7 axpby. */
+int sparsh_bench_op(sparsh_handle h, int op, int level, int reps, double *avg_seconds);
+
+/* device memory helpers so a host language needs no HIP binding of its own */
+int sparsh_dev_alloc(sparsh_handle h, long nbytes, void **out);
+int sparsh_dev_free(sparsh_handle h, void *p);
+int sparsh_h2d(sparsh_handle h, void *dst_dev, const void *src, long nbytes);
+int sparsh_d2h(sparsh_handle h, void *dst, const void *src_dev, long nbytes);
+int sparsh_sync(sparsh_handle h);
+
+/* Per-kernel-class device time of the last sparsh_solve_dev call when profiling is enabled
+ * (sparsh_profile(h,1)): HIP-event time of every fine-level fused Jacobi sweep launch.
+ * out[0] = launches, out[1] = total seconds, out[2] = rows, out[3] = nnz of that level. */
+int sparsh_profile(sparsh_handle h, int enable);
+int sparsh_profile_read(sparsh_handle h, double *out4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

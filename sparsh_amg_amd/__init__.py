@@ -1,1 +1,404 @@
-"""placeholder; replaced below once the native library exists"""
+"""sparsh_amg_amd -- MI355X-native AMG solve phase behind the SParSH-AMG API.
+
+This package is a thin ctypes binding of ``libsparsh_amg.so`` (HIP kernels for gfx950 + host
+setup + C ABI, sources in ``csrc/``; C ABI in ``include/sparsh_amg.h``).  There is no Python or
+CPU compute path: if the native library is missing, importing fails loudly, and if no GPU is
+visible every solver call raises.
+
+Python names mirror the reference's C++ entry points (include/AMG.hpp:40-85 of
+cmgcds/SParSH-AMG): ``AMG_Solver_CPU_GPU_MI(A, b, x)``, ``Solver_PCG_4(A, b, x)`` ...
+where ``A`` is an :class:`sp_matrix_mg`, and ``b``/``x`` are float64 numpy vectors (``x`` is
+the initial guess on entry and is overwritten with the solution, as in the reference).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import problems  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsparsh_amg.so")
+
+SPARSH_AMG, SPARSH_CG, SPARSH_PCG, SPARSH_BICG, SPARSH_PBICG = 0, 1, 2, 3, 4
+METHODS = {"amg": SPARSH_AMG, "cg": SPARSH_CG, "pcg": SPARSH_PCG, "bicg": SPARSH_BICG, "pbicg": SPARSH_PBICG}
+SPARSH_OK, SPARSH_EINVAL, SPARSH_ENODEV, SPARSH_ESTATE, SPARSH_ENUMERIC, SPARSH_ENOCONV, SPARSH_ECOMM = 0, -1, -2, -3, -4, -5, -6
+
+c_int_p = C.POINTER(C.c_int)
+c_dbl_p = C.POINTER(C.c_double)
+
+
+class SparshError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"sparsh error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    """``sparsh_params`` (include/sparsh_amg.h); defaults = macros of the reference's AMG.hpp:15-27."""
+
+    _fields_ = [
+        ("omega", C.c_double),
+        ("tol", C.c_double),
+        ("sweeps", C.c_int),
+        ("max_levels", C.c_int),
+        ("limit_upper", C.c_int),
+        ("limit_lower", C.c_int),
+        ("coarsening", C.c_int),
+        ("max_iter", C.c_int),
+        ("coarse_limit", C.c_int),
+        ("host_threads", C.c_int),
+        ("device", C.c_int),
+        ("print_setup", C.c_int),
+        ("print_solve", C.c_int),
+        ("check_every", C.c_int),
+        ("use_graph", C.c_int),
+    ]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C sparsh_amg_amd/csrc`).  There is no pure-Python/CPU fallback."
+        )
+    L = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    P = C.POINTER
+    sig = {
+        "sparsh_last_error": (C.c_char_p, []),
+        "sparsh_version": (C.c_int, []),
+        "sparsh_device_count": (C.c_int, []),
+        "sparsh_default_params": (None, [P(Params)]),
+        "sparsh_create_csr": (C.c_int, [C.c_int, C.c_int, c_int_p, c_int_p, c_dbl_p, P(H)]),
+        "sparsh_destroy": (None, [H]),
+        "sparsh_setup": (C.c_int, [H, P(Params)]),
+        "sparsh_setup_host": (C.c_int, [H, P(Params)]),
+        "sparsh_num_levels": (C.c_int, [H]),
+        "sparsh_level_info": (C.c_int, [H, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p]),
+        "sparsh_level_csr": (C.c_int, [H, C.c_int, C.c_int, c_int_p, c_int_p, c_dbl_p]),
+        "sparsh_coarse_inverse": (C.c_int, [H, c_dbl_p]),
+        "sparsh_setup_seconds": (C.c_double, [H]),
+        "sparsh_vcycle": (C.c_int, [H, c_dbl_p, c_dbl_p, C.c_int, c_dbl_p, C.c_int, c_int_p]),
+        "sparsh_solve": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, C.c_int, c_int_p]),
+        "sparsh_solve_dev": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_int, c_dbl_p, C.c_int, c_int_p, c_dbl_p]),
+        "sparsh_krylov_init_dev": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p]),
+        "sparsh_krylov_step_dev": (C.c_int, [H, C.c_int, c_int_p, c_dbl_p]),
+        "sparsh_krylov_history": (C.c_int, [H, c_dbl_p, C.c_int, c_int_p]),
+        "sparsh_op_spmv": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p]),
+        "sparsh_op_jacobi": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p, C.c_int, C.c_int]),
+        "sparsh_op_residual": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p]),
+        "sparsh_op_resnorm": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p]),
+        "sparsh_op_restrict": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p]),
+        "sparsh_op_prolong": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p]),
+        "sparsh_op_coarse": (C.c_int, [H, c_dbl_p, c_dbl_p]),
+        "sparsh_op_dot": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p]),
+        "sparsh_op_nrm2": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p]),
+        "sparsh_op_axpby": (C.c_int, [H, C.c_int, C.c_double, c_dbl_p, C.c_double, c_dbl_p]),
+        "sparsh_bench_op": (C.c_int, [H, C.c_int, C.c_int, C.c_int, c_dbl_p]),
+        "sparsh_dev_alloc": (C.c_int, [H, C.c_long, P(C.c_void_p)]),
+        "sparsh_dev_free": (C.c_int, [H, C.c_void_p]),
+        "sparsh_h2d": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_long]),
+        "sparsh_d2h": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_long]),
+        "sparsh_sync": (C.c_int, [H]),
+        "sparsh_profile": (C.c_int, [H, C.c_int]),
+        "sparsh_profile_read": (C.c_int, [H, c_dbl_p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+lib = _load()
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_dbl_p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_int_p)
+
+
+def _check(rc, allow=()):
+    if rc != SPARSH_OK and rc not in allow:
+        raise SparshError(rc, lib.sparsh_last_error().decode())
+    return rc
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    lib.sparsh_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(f"sparsh_params has no field {k}")
+        setattr(p, k, v)
+    return p
+
+
+def device_count() -> int:
+    return lib.sparsh_device_count()
+
+
+class sp_matrix_mg:
+    """Host CSR container named after the reference's class (include/AMG_cpu_matrix.hpp:12-51).
+
+    Holds rowptr/colindex/val as contiguous int32/float64 numpy arrays (aliased by the native
+    handle, never copied) and owns the native solver handle.
+    """
+
+    def __init__(self, rowptr, colindex, val, ncol=None):
+        self.rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        self.colindex = np.ascontiguousarray(colindex, dtype=np.int32)
+        self.val = np.ascontiguousarray(val, dtype=np.float64)
+        self.nrow = len(self.rowptr) - 1
+        self.ncol = self.nrow if ncol is None else int(ncol)
+        self.nnz = int(self.rowptr[-1])
+        if len(self.colindex) < self.nnz or len(self.val) < self.nnz:
+            raise ValueError("colindex/val shorter than rowptr[-1]")
+        h = C.c_void_p()
+        _check(lib.sparsh_create_csr(self.nrow, self.ncol, _ip(self.rowptr), _ip(self.colindex), _dp(self.val), C.byref(h)))
+        self._h = h
+        self.params = None
+
+    # -- lifecycle -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.sparsh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- setup -----------------------------------------------------------------------------
+    def setup(self, params: Params | None = None, host_only: bool = False):
+        """AMG_solver_setup_jacobi + GPU_Allocations (host_only: hierarchy only, no GPU)."""
+        self.params = params if params is not None else default_params()
+        fn = lib.sparsh_setup_host if host_only else lib.sparsh_setup
+        _check(fn(self._h, C.byref(self.params)))
+        return self
+
+    @property
+    def nlevels(self):
+        return lib.sparsh_num_levels(self._h)
+
+    @property
+    def setup_seconds(self):
+        return lib.sparsh_setup_seconds(self._h)
+
+    def level_info(self, level):
+        a = [C.c_int() for _ in range(4)]
+        _check(lib.sparsh_level_info(self._h, level, *[C.byref(v) for v in a]))
+        return dict(nrow=a[0].value, nnz=a[1].value, p_ncol=a[2].value, p_nnz=a[3].value)
+
+    def level_csr(self, level, which="A"):
+        info = self.level_info(level)
+        nrow = info["nrow"]
+        nnz = info["nnz"] if which == "A" else info["p_nnz"]
+        rp = np.zeros(nrow + 1, dtype=np.int32)
+        ci = np.zeros(max(nnz, 1), dtype=np.int32)
+        v = np.zeros(max(nnz, 1), dtype=np.float64)
+        _check(lib.sparsh_level_csr(self._h, level, 0 if which == "A" else 1, _ip(rp), _ip(ci), _dp(v)))
+        ncol = nrow if which == "A" else info["p_ncol"]
+        return rp, ci[:nnz], v[:nnz], ncol
+
+    def level_scipy(self, level, which="A"):
+        import scipy.sparse as sp
+
+        rp, ci, v, ncol = self.level_csr(level, which)
+        return sp.csr_matrix((v, ci, rp), shape=(len(rp) - 1, ncol))
+
+    def coarse_inverse(self):
+        n = self.level_info(self.nlevels - 1)["nrow"]
+        inv = np.zeros((n, n))
+        _check(lib.sparsh_coarse_inverse(self._h, _dp(inv)))
+        return inv
+
+    # -- solvers (host vectors) ------------------------------------------------------------
+    def vcycle(self, b, x, iterations=-1, hist_cap=8192):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        hist = np.zeros(hist_cap)
+        n = C.c_int()
+        rc = _check(lib.sparsh_vcycle(self._h, _dp(b), _dp(x), iterations, _dp(hist), hist_cap, C.byref(n)), allow=(SPARSH_ENOCONV,))
+        return hist[: min(n.value, hist_cap)].copy(), rc
+
+    def solve(self, method, b, x, hist_cap=8192):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        assert x.dtype == np.float64 and x.flags.c_contiguous
+        hist = np.zeros(hist_cap)
+        n = C.c_int()
+        m = METHODS[method] if isinstance(method, str) else method
+        rc = _check(lib.sparsh_solve(self._h, m, _dp(b), _dp(x), _dp(hist), hist_cap, C.byref(n)), allow=(SPARSH_ENOCONV,))
+        return hist[: min(n.value, hist_cap)].copy(), rc
+
+    # -- device-resident path (bench) ------------------------------------------------------
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        _check(lib.sparsh_dev_alloc(self._h, nbytes, C.byref(p)))
+        return p
+
+    def dev_free(self, p):
+        _check(lib.sparsh_dev_free(self._h, p))
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        _check(lib.sparsh_h2d(self._h, dptr, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def d2h(self, arr, dptr):
+        _check(lib.sparsh_d2h(self._h, arr.ctypes.data_as(C.c_void_p), dptr, arr.nbytes))
+
+    def sync(self):
+        _check(lib.sparsh_sync(self._h))
+
+    def solve_dev(self, method, b_dev, x_dev, max_iters=0, hist_cap=8192):
+        hist = np.zeros(hist_cap)
+        n = C.c_int()
+        sec = C.c_double()
+        m = METHODS[method] if isinstance(method, str) else method
+        rc = _check(
+            lib.sparsh_solve_dev(self._h, m, b_dev, x_dev, max_iters, _dp(hist), hist_cap, C.byref(n), C.byref(sec)),
+            allow=(SPARSH_ENOCONV,),
+        )
+        return hist[: min(n.value, hist_cap)].copy(), n.value, sec.value, rc
+
+    def krylov_init_dev(self, method, b_dev, x_dev):
+        m = METHODS[method] if isinstance(method, str) else method
+        _check(lib.sparsh_krylov_init_dev(self._h, m, b_dev, x_dev))
+
+    def krylov_step_dev(self, nsteps):
+        done = C.c_int()
+        res = C.c_double()
+        _check(lib.sparsh_krylov_step_dev(self._h, nsteps, C.byref(done), C.byref(res)))
+        return done.value, res.value
+
+    def krylov_history(self, hist_cap=8192):
+        hist = np.zeros(hist_cap)
+        n = C.c_int()
+        _check(lib.sparsh_krylov_history(self._h, _dp(hist), hist_cap, C.byref(n)))
+        return hist[: min(n.value, hist_cap)].copy()
+
+    def profile(self, enable=True):
+        _check(lib.sparsh_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        out = np.zeros(4)
+        _check(lib.sparsh_profile_read(self._h, _dp(out)))
+        return dict(launches=int(out[0]), seconds=out[1], nrow=int(out[2]), nnz=int(out[3]))
+
+    def bench_op(self, op, level=0, reps=20):
+        ops = {"spmv": 0, "jacobi": 1, "residual": 2, "restrict": 3, "prolong": 4, "coarse": 5, "dot": 6, "axpby": 7}
+        sec = C.c_double()
+        _check(lib.sparsh_bench_op(self._h, ops[op] if isinstance(op, str) else op, level, reps, C.byref(sec)))
+        return sec.value
+
+    # -- operators (host vectors; kernel parity tests) -------------------------------------
+    def op_spmv(self, level, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros(self.level_info(level)["nrow"])
+        _check(lib.sparsh_op_spmv(self._h, level, _dp(x), _dp(y)))
+        return y
+
+    def op_jacobi(self, level, b, x, sweeps, x_is_zero=False):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.array(x, dtype=np.float64)
+        _check(lib.sparsh_op_jacobi(self._h, level, _dp(b), _dp(x), sweeps, 1 if x_is_zero else 0))
+        return x
+
+    def op_residual(self, level, b, x):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        r = np.zeros_like(b)
+        _check(lib.sparsh_op_residual(self._h, level, _dp(b), _dp(x), _dp(r)))
+        return r
+
+    def op_resnorm(self, level, b, x):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = C.c_double()
+        _check(lib.sparsh_op_resnorm(self._h, level, _dp(b), _dp(x), C.byref(out)))
+        return out.value
+
+    def op_restrict(self, level, r):
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        bc = np.zeros(self.level_info(level + 1)["nrow"])
+        _check(lib.sparsh_op_restrict(self._h, level, _dp(r), _dp(bc)))
+        return bc
+
+    def op_prolong(self, level, xc, xf):
+        xc = np.ascontiguousarray(xc, dtype=np.float64)
+        xf = np.array(xf, dtype=np.float64)
+        _check(lib.sparsh_op_prolong(self._h, level, _dp(xc), _dp(xf)))
+        return xf
+
+    def op_coarse(self, b):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.zeros_like(b)
+        _check(lib.sparsh_op_coarse(self._h, _dp(b), _dp(x)))
+        return x
+
+    def op_dot(self, x, y):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        out = C.c_double()
+        _check(lib.sparsh_op_dot(self._h, len(x), _dp(x), _dp(y), C.byref(out)))
+        return out.value
+
+    def op_nrm2(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = C.c_double()
+        _check(lib.sparsh_op_nrm2(self._h, len(x), _dp(x), C.byref(out)))
+        return out.value
+
+    def op_axpby(self, a, x, b, y):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.array(y, dtype=np.float64)
+        _check(lib.sparsh_op_axpby(self._h, len(x), a, _dp(x), b, _dp(y)))
+        return y
+
+
+# ---- entry points named as in the reference's include/AMG.hpp:40-85 --------------------------
+# Each call redoes the setup, as the reference does (solver objects live inside one call).
+
+def _entry(method):
+    def run(A: sp_matrix_mg, b, x, params: Params | None = None):
+        A.setup(params)
+        hist, _ = A.solve(method, b, x)
+        return hist
+
+    return run
+
+
+AMG_Solver_CPU_baseline = _entry("amg")
+AMG_Solver_1 = AMG_Solver_CPU_baseline
+AMG_Solver_CPU_GPU_CI = _entry("amg")
+AMG_Solver_CPU_GPU_MI = _entry("amg")
+Solver_CG_1 = Solver_CG_2 = _entry("cg")
+Solver_PCG_1 = Solver_PCG_2 = Solver_PCG_3 = Solver_PCG_4 = _entry("pcg")
+Solver_BiCG_1 = _entry("bicg")
+Solver_PBiCG_1 = Solver_PBiCG_2 = Solver_PBiCG_3 = Solver_PBiCG_4 = _entry("pbicg")
+
+
+def readcoo(matrixfile: str, rhsfile: str):
+    """Native text format of the reference (src/AMG_file_read.cpp:39-72) -> (sp_matrix_mg, b)."""
+    with open(matrixfile) as f:
+        nrow, ncol, nnz = (int(t) for t in f.readline().split())
+        data = np.loadtxt(f, dtype=np.float64, ndmin=2)
+    if data.shape[0] != nnz:
+        raise IOError(f"{matrixfile}: header says {nnz} entries, file holds {data.shape[0]}")
+    rows = data[:, 0].astype(np.int64)
+    if np.any(np.diff(rows) < 0):
+        raise IOError("readcoo requires entries sorted by row (as the reference does)")
+    rowptr = np.zeros(nrow + 1, dtype=np.int32)
+    np.cumsum(np.bincount(rows, minlength=nrow), out=rowptr[1:])
+    with open(rhsfile) as f:
+        n = int(f.readline().split()[0])
+        b = np.loadtxt(f, dtype=np.float64)
+    assert n == nrow
+    return sp_matrix_mg(rowptr, data[:, 1].astype(np.int32), data[:, 2].copy(), ncol=ncol), b[:nrow].copy()

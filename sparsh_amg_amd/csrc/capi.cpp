@@ -1,0 +1,473 @@
+// capi.cpp -- extern "C" surface declared in include/sparsh_amg.h.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+
+#include "../../include/sparsh_amg.h"
+#include "engine.hpp"
+
+using namespace sparsh;
+
+struct sparsh_handle_s {
+    std::unique_ptr<Engine> eng;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : dflt;
+}
+
+double env_dbl(const char *name, double dflt)
+{
+    const char *v = std::getenv(name);
+    return (v && *v) ? std::atof(v) : dflt;
+}
+
+// RAII device buffer for the host-vector operator wrappers
+struct DBuf {
+    Engine &E;
+    double *p = nullptr;
+    size_t n;
+    DBuf(Engine &e, size_t count, const double *src = nullptr) : E(e), n(count)
+    {
+        p = static_cast<double *>(E.dalloc(count * sizeof(double)));
+        if (p && src) (void)hipMemcpy(p, src, count * sizeof(double), hipMemcpyHostToDevice);
+    }
+    ~DBuf() { E.dfree(p); }
+    bool get(double *dst)
+    {
+        (void)hipStreamSynchronize(E.stream());
+        return hipMemcpy(dst, p, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+};
+
+#define REQUIRE_READY(h)                                                         \
+    if (!(h) || !(h)->eng) return fail(SPARSH_EINVAL, "null handle");            \
+    if (!(h)->eng->ready()) return fail(SPARSH_ESTATE, "sparsh_setup has not been called (or failed)")
+
+#define REQUIRE_LEVEL(h, l) \
+    if ((l) < 0 || (l) >= (int)(h)->eng->host().levels.size()) return fail(SPARSH_EINVAL, "level out of range")
+
+#define REQUIRE_HOST(h)                                               \
+    if (!(h) || !(h)->eng) return fail(SPARSH_EINVAL, "null handle"); \
+    if (!(h)->eng->host_ready()) return fail(SPARSH_ESTATE, "sparsh_setup / sparsh_setup_host has not been called (or failed)")
+
+}  // namespace
+
+extern "C" {
+
+const char *sparsh_last_error(void) { return g_err.c_str(); }
+
+int sparsh_version(void) { return 100; }
+
+int sparsh_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void sparsh_default_params(sparsh_params *p)
+{
+    if (!p) return;
+    // reference macros, include/AMG.hpp:15-27
+    p->omega = env_dbl("SPARSH_OMEGA", 0.66667);
+    p->tol = env_dbl("SPARSH_TOL", 1e-8);
+    p->sweeps = env_int("SPARSH_NU", 6 + 1);  // smooth_iter + 1: the CPU path's count (src/AMG_smoothers.cpp:59-60)
+    p->max_levels = env_int("SPARSH_LEVELS", 6);
+    p->limit_upper = 4000;
+    p->limit_lower = 2000;
+    p->coarsening = 0;
+    if (const char *c = std::getenv("SPARSH_COARSENING")) p->coarsening = (std::strcmp(c, "beck") == 0) ? 1 : 0;
+    p->max_iter = env_int("SPARSH_MAXIT", 100000);
+    p->coarse_limit = env_int("SPARSH_COARSE_LIMIT", 8192);
+    p->host_threads = env_int("SPARSH_THREADS", 0);
+    p->device = -1;
+    if (const char *lr = std::getenv("LOCAL_RANK")) p->device = std::atoi(lr);
+    const int pr = env_int("SPARSH_PRINT", 1);
+    p->print_setup = pr;
+    p->print_solve = pr;
+    p->check_every = 1;
+    p->use_graph = env_int("SPARSH_GRAPH", 0);
+}
+
+int sparsh_create_csr(int nrow, int ncol, const int *rowptr, const int *colindex, const double *val, sparsh_handle *out)
+{
+    if (!out || !rowptr || nrow <= 0 || ncol <= 0) return fail(SPARSH_EINVAL, "bad CSR arguments");
+    if (rowptr[0] != 0 || rowptr[nrow] < 0) return fail(SPARSH_EINVAL, "rowptr must start at 0");
+    if (rowptr[nrow] > 0 && (!colindex || !val)) return fail(SPARSH_EINVAL, "null colindex/val");
+    auto *h = new sparsh_handle_s;
+    h->eng.reset(new Engine(nrow, ncol, rowptr, colindex, val));
+    *out = h;
+    return SPARSH_OK;
+}
+
+void sparsh_destroy(sparsh_handle h) { delete h; }
+
+int sparsh_setup(sparsh_handle h, const sparsh_params *p)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    sparsh_params prm;
+    if (p)
+        prm = *p;
+    else
+        sparsh_default_params(&prm);
+    if (prm.sweeps < 1 || prm.max_levels < 1 || prm.limit_upper < 1) return fail(SPARSH_EINVAL, "bad params");
+    int rc = h->eng->setup(prm);
+    if (rc != SPARSH_OK) return fail(rc, h->eng->error);
+    return rc;
+}
+
+int sparsh_setup_host(sparsh_handle h, const sparsh_params *p)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    sparsh_params prm;
+    if (p)
+        prm = *p;
+    else
+        sparsh_default_params(&prm);
+    if (prm.sweeps < 1 || prm.max_levels < 1 || prm.limit_upper < 1) return fail(SPARSH_EINVAL, "bad params");
+    int rc = h->eng->setup_host(prm);
+    if (rc != SPARSH_OK) return fail(rc, h->eng->error);
+    return rc;
+}
+
+int sparsh_num_levels(sparsh_handle h)
+{
+    if (!h || !h->eng || !h->eng->host_ready()) return 0;
+    return (int)h->eng->host().levels.size();
+}
+
+int sparsh_level_info(sparsh_handle h, int level, int *nrow, int *nnz, int *p_ncol, int *p_nnz)
+{
+    REQUIRE_HOST(h);
+    REQUIRE_LEVEL(h, level);
+    const HostLevel &L = h->eng->host().levels[level];
+    if (nrow) *nrow = L.A.nrow;
+    if (nnz) *nnz = L.A.nnz();
+    if (p_ncol) *p_ncol = L.P.rowptr ? L.P.ncol : 0;
+    if (p_nnz) *p_nnz = L.P.rowptr ? L.P.nnz() : 0;
+    return SPARSH_OK;
+}
+
+int sparsh_level_csr(sparsh_handle h, int level, int which, int *rowptr, int *colindex, double *val)
+{
+    REQUIRE_HOST(h);
+    REQUIRE_LEVEL(h, level);
+    const HostLevel &L = h->eng->host().levels[level];
+    const HostCsr &M = (which == 0) ? L.A : L.P;
+    if (!M.rowptr) return fail(SPARSH_EINVAL, "no such matrix on this level");
+    std::memcpy(rowptr, M.rowptr, sizeof(int) * ((size_t)M.nrow + 1));
+    std::memcpy(colindex, M.col, sizeof(int) * (size_t)M.nnz());
+    std::memcpy(val, M.val, sizeof(double) * (size_t)M.nnz());
+    return SPARSH_OK;
+}
+
+int sparsh_coarse_inverse(sparsh_handle h, double *inv)
+{
+    REQUIRE_HOST(h);
+    const HostHierarchy &H = h->eng->host();
+    if (H.coarse_inverse.empty()) return fail(SPARSH_ESTATE, "host copy of the inverse was released by sparsh_setup; use sparsh_setup_host");
+    std::memcpy(inv, H.coarse_inverse.data(), sizeof(double) * (size_t)H.nL * H.nL);
+    return SPARSH_OK;
+}
+
+double sparsh_setup_seconds(sparsh_handle h) { return (h && h->eng) ? h->eng->setup_seconds : 0.0; }
+
+int sparsh_vcycle(sparsh_handle h, const double *b, double *x, int iterations, double *hist, int hist_cap, int *ncycles)
+{
+    REQUIRE_READY(h);
+    Engine &E = *h->eng;
+    const size_t n = (size_t)E.n0();
+    DBuf db(E, n, b), dx(E, n, x);
+    if (!db.p || !dx.p) return fail(SPARSH_ENODEV, E.error);
+    int rc = E.amg_solve_dev(db.p, dx.p, iterations, hist, hist_cap, ncycles);
+    dx.get(x);
+    if (rc != SPARSH_OK) return fail(rc, E.error);
+    return rc;
+}
+
+int sparsh_solve(sparsh_handle h, int method, const double *b, double *x, double *hist, int hist_cap, int *iters)
+{
+    REQUIRE_READY(h);
+    Engine &E = *h->eng;
+    const size_t n = (size_t)E.n0();
+    DBuf db(E, n, b), dx(E, n, x);
+    if (!db.p || !dx.p) return fail(SPARSH_ENODEV, E.error);
+    int rc = E.solve_dev(method, db.p, dx.p, 0, hist, hist_cap, iters, nullptr);
+    dx.get(x);
+    if (rc != SPARSH_OK) return fail(rc, E.error);
+    return rc;
+}
+
+int sparsh_solve_dev(sparsh_handle h, int method, const double *b_dev, double *x_dev, int max_iters, double *hist, int hist_cap,
+                     int *iters, double *seconds)
+{
+    REQUIRE_READY(h);
+    int rc = h->eng->solve_dev(method, b_dev, x_dev, max_iters, hist, hist_cap, iters, seconds);
+    if (rc != SPARSH_OK) return fail(rc, h->eng->error);
+    return rc;
+}
+
+int sparsh_krylov_init_dev(sparsh_handle h, int method, const double *b_dev, double *x_dev)
+{
+    REQUIRE_READY(h);
+    if (method != SPARSH_CG && method != SPARSH_PCG) return fail(SPARSH_EINVAL, "stepwise interface covers SPARSH_CG and SPARSH_PCG");
+    int rc = h->eng->pcg_init(b_dev, x_dev, method == SPARSH_PCG);
+    if (rc != SPARSH_OK) return fail(rc, h->eng->error);
+    return rc;
+}
+
+int sparsh_krylov_step_dev(sparsh_handle h, int nsteps, int *done, double *residual)
+{
+    REQUIRE_READY(h);
+    int rc = h->eng->pcg_steps(nsteps, done);
+    if (residual) *residual = h->eng->krylov_residual();
+    if (rc != SPARSH_OK) return fail(rc, h->eng->error);
+    return rc;
+}
+
+int sparsh_krylov_history(sparsh_handle h, double *hist, int hist_cap, int *iters)
+{
+    REQUIRE_READY(h);
+    int c = h->eng->krylov_hist(hist, hist_cap);
+    if (iters) *iters = c;
+    return SPARSH_OK;
+}
+
+int sparsh_op_spmv(sparsh_handle h, int level, const double *x, double *y)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    Engine &E = *h->eng;
+    const DevLevel &L = E.level(level);
+    DBuf dx(E, (size_t)L.A.ncol, x), dy(E, (size_t)L.n);
+    E.op_spmv(level, dx.p, dy.p);
+    return dy.get(y) ? SPARSH_OK : fail(SPARSH_ENODEV, "D2H failed");
+}
+
+int sparsh_op_jacobi(sparsh_handle h, int level, const double *b, double *x, int sweeps, int x_is_zero)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    if (sweeps < 0) return fail(SPARSH_EINVAL, "sweeps < 0");
+    Engine &E = *h->eng;
+    const size_t n = (size_t)E.level(level).n;
+    DBuf db(E, n, b), dx(E, n, x), dt(E, n);
+    E.op_jacobi(level, db.p, dx.p, dt.p, sweeps, x_is_zero != 0);
+    return dx.get(x) ? SPARSH_OK : fail(SPARSH_ENODEV, "D2H failed");
+}
+
+int sparsh_op_residual(sparsh_handle h, int level, const double *b, const double *x, double *r)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    Engine &E = *h->eng;
+    const size_t n = (size_t)E.level(level).n;
+    DBuf db(E, n, b), dx(E, n, x), dr(E, n);
+    E.op_residual(level, db.p, dx.p, dr.p);
+    return dr.get(r) ? SPARSH_OK : fail(SPARSH_ENODEV, "D2H failed");
+}
+
+int sparsh_op_resnorm(sparsh_handle h, int level, const double *b, const double *x, double *nrm)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    Engine &E = *h->eng;
+    const size_t n = (size_t)E.level(level).n;
+    DBuf db(E, n, b), dx(E, n, x);
+    *nrm = E.op_resnorm(level, db.p, dx.p);
+    return SPARSH_OK;
+}
+
+int sparsh_op_restrict(sparsh_handle h, int level, const double *r, double *bc)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    if (level + 1 >= h->eng->nlevels()) return fail(SPARSH_EINVAL, "no coarser level");
+    Engine &E = *h->eng;
+    DBuf dr(E, (size_t)E.level(level).n, r), dc(E, (size_t)E.level(level + 1).n);
+    E.op_restrict(level, dr.p, dc.p);
+    return dc.get(bc) ? SPARSH_OK : fail(SPARSH_ENODEV, "D2H failed");
+}
+
+int sparsh_op_prolong(sparsh_handle h, int level, const double *xc, double *xf)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    if (level + 1 >= h->eng->nlevels()) return fail(SPARSH_EINVAL, "no coarser level");
+    Engine &E = *h->eng;
+    DBuf dc(E, (size_t)E.level(level + 1).n, xc), df(E, (size_t)E.level(level).n, xf);
+    E.op_prolong(level, dc.p, df.p);
+    return df.get(xf) ? SPARSH_OK : fail(SPARSH_ENODEV, "D2H failed");
+}
+
+int sparsh_op_coarse(sparsh_handle h, const double *b, double *x)
+{
+    REQUIRE_READY(h);
+    Engine &E = *h->eng;
+    const size_t n = (size_t)E.level(E.nlevels() - 1).n;
+    DBuf db(E, n, b), dx(E, n);
+    E.op_coarse(db.p, dx.p);
+    return dx.get(x) ? SPARSH_OK : fail(SPARSH_ENODEV, "D2H failed");
+}
+
+int sparsh_op_dot(sparsh_handle h, int n, const double *x, const double *y, double *out)
+{
+    REQUIRE_READY(h);
+    if (n <= 0) return fail(SPARSH_EINVAL, "n <= 0");
+    Engine &E = *h->eng;
+    DBuf dx(E, (size_t)n, x), dy(E, (size_t)n, y);
+    *out = E.op_dot(n, dx.p, dy.p);
+    return SPARSH_OK;
+}
+
+int sparsh_op_nrm2(sparsh_handle h, int n, const double *x, double *out)
+{
+    double d = 0.0;
+    int rc = sparsh_op_dot(h, n, x, x, &d);
+    if (rc == SPARSH_OK) *out = std::sqrt(d);
+    return rc;
+}
+
+int sparsh_op_axpby(sparsh_handle h, int n, double a, const double *x, double bcoef, double *y)
+{
+    REQUIRE_READY(h);
+    if (n <= 0) return fail(SPARSH_EINVAL, "n <= 0");
+    Engine &E = *h->eng;
+    DBuf dx(E, (size_t)n, x), dy(E, (size_t)n, y);
+    launch_axpby(n, a, dx.p, bcoef, dy.p, E.stream());
+    return dy.get(y) ? SPARSH_OK : fail(SPARSH_ENODEV, "D2H failed");
+}
+
+int sparsh_bench_op(sparsh_handle h, int op, int level, int reps, double *avg_seconds)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    if (reps <= 0 || !avg_seconds) return fail(SPARSH_EINVAL, "bad reps");
+    Engine &E = *h->eng;
+    const DevLevel &L = E.level(level);
+    const size_t n = (size_t)L.n;
+    const bool has_coarse = level + 1 < E.nlevels();
+    if ((op == 3 || op == 4) && !has_coarse) return fail(SPARSH_EINVAL, "no coarser level");
+    const size_t nc = has_coarse ? (size_t)E.level(level + 1).n : 1;
+    DBuf x(E, n), y(E, n), b(E, n), c(E, nc);
+    std::vector<double> ones(std::max(n, nc), 1.0);
+    (void)hipMemcpy(x.p, ones.data(), n * 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(b.p, ones.data(), n * 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(y.p, ones.data(), n * 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(c.p, ones.data(), nc * 8, hipMemcpyHostToDevice);
+    hipStream_t st = E.stream();
+    auto run = [&]() {
+        switch (op) {
+        case 0: E.op_spmv(level, x.p, y.p); break;
+        case 1: {
+            CsrArgs a;
+            a.x = x.p;
+            a.b = b.p;
+            a.d = L.diag;
+            a.y = y.p;
+            a.omega = E.params().omega;
+            launch_csr(L.A, OP_JACOBI, a, L.fine, st);
+        } break;
+        case 2: E.op_residual(level, b.p, x.p, y.p); break;
+        case 3: E.op_restrict(level, x.p, c.p); break;
+        case 4: E.op_prolong(level, c.p, y.p); break;
+        case 5: E.op_coarse(E.level(E.nlevels() - 1).b ? E.level(E.nlevels() - 1).b : b.p, E.level(E.nlevels() - 1).r); break;
+        case 6: {
+            int nb = 0;
+            launch_dot((int)n, x.p, b.p, E.level(0).r, &nb, st);
+        } break;
+        case 7: launch_axpby((int)n, 0.5, x.p, 0.5, y.p, st); break;
+        default: break;
+        }
+    };
+    if (op < 0 || op > 7) return fail(SPARSH_EINVAL, "unknown op");
+    for (int i = 0; i < 3; ++i) run();
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, st);
+    for (int i = 0; i < reps; ++i) run();
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_seconds = ms * 1e-3 / reps;
+    return SPARSH_OK;
+}
+
+int sparsh_dev_alloc(sparsh_handle h, long nbytes, void **out)
+{
+    if (!h || !h->eng || !out || nbytes < 0) return fail(SPARSH_EINVAL, "bad arguments");
+    *out = h->eng->dalloc((size_t)nbytes);
+    return *out ? SPARSH_OK : fail(SPARSH_ENODEV, h->eng->error);
+}
+
+int sparsh_dev_free(sparsh_handle h, void *p)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    h->eng->dfree(p);
+    return SPARSH_OK;
+}
+
+int sparsh_h2d(sparsh_handle h, void *dst_dev, const void *src, long nbytes)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    if (hipMemcpy(dst_dev, src, (size_t)nbytes, hipMemcpyHostToDevice) != hipSuccess) return fail(SPARSH_ENODEV, "H2D failed");
+    return SPARSH_OK;
+}
+
+int sparsh_d2h(sparsh_handle h, void *dst, const void *src_dev, long nbytes)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    if (h->eng->stream()) (void)hipStreamSynchronize(h->eng->stream());
+    if (hipMemcpy(dst, src_dev, (size_t)nbytes, hipMemcpyDeviceToHost) != hipSuccess) return fail(SPARSH_ENODEV, "D2H failed");
+    return SPARSH_OK;
+}
+
+int sparsh_sync(sparsh_handle h)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    if (h->eng->stream() && hipStreamSynchronize(h->eng->stream()) != hipSuccess) return fail(SPARSH_ENODEV, "sync failed");
+    return SPARSH_OK;
+}
+
+int sparsh_profile(sparsh_handle h, int enable)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    h->eng->prof.enabled = enable != 0;
+    return SPARSH_OK;
+}
+
+int sparsh_profile_read(sparsh_handle h, double *out4)
+{
+    REQUIRE_READY(h);
+    out4[0] = h->eng->prof.launches;
+    out4[1] = h->eng->prof.seconds;
+    out4[2] = h->eng->level(0).n;
+    out4[3] = h->eng->level(0).A.nnz;
+    return SPARSH_OK;
+}
+
+}  // extern "C"

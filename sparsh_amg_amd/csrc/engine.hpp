@@ -1,0 +1,123 @@
+// engine.hpp -- device-resident AMG hierarchy + V-cycle + Krylov loops (single GPU).
+// Mirrors the behaviour of AMG_GPU1_solver ("MI": whole hierarchy resident,
+// src/AMG_gpu_phases_2.cu:13-240) with the arithmetic of the CPU path
+// (src/AMG_phases.cpp:151-230, src/AMG_main_solvers.cpp:47-458).
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "../../include/sparsh_amg.h"
+#include "host_setup.hpp"
+#include "kernels.hpp"
+
+namespace sparsh {
+
+struct DevLevel {
+    int n = 0;
+    DevCsr A, P, R;
+    bool P_is_aggregation = false;
+    double *diag = nullptr;
+    double *x = nullptr, *x2 = nullptr;  // ping-pong solution buffers (Jacobi reads old, writes new)
+    double *b = nullptr;                 // rhs of this level (level 0: points at the caller's vector)
+    double *r = nullptr;                 // residual
+    bool fine = false;                   // operator larger than the on-die caches: stream with nt loads
+};
+
+struct KrylovState {
+    bool active = false, precond = false;
+    const double *b = nullptr;
+    double *x = nullptr;
+    int count = 0;
+    double r1 = 0.0;
+};
+
+struct ProfileData {
+    bool enabled = false;
+    std::vector<hipEvent_t> ev;  // pairs
+    size_t used = 0;
+    double launches = 0, seconds = 0;
+};
+
+class Engine {
+public:
+    Engine(int nrow, int ncol, const int *rowptr, const int *col, const double *val);
+    ~Engine();
+
+    int setup_host(const sparsh_params &p);  // hierarchy on the host only (no device needed)
+    int setup(const sparsh_params &p);       // setup_host + upload to HBM
+    bool ready() const { return ready_; }
+    bool host_ready() const { return host_ready_; }
+    int nlevels() const { return (int)lev_.size(); }
+    const HostHierarchy &host() const { return H_; }
+    const sparsh_params &params() const { return prm_; }
+    hipStream_t stream() const { return st_; }
+    const DevLevel &level(int l) const { return lev_[l]; }
+    int n0() const { return A0_.nrow; }
+
+    // solvers on device vectors; return SPARSH_* code; iterations through *iters
+    int solve_dev(int method, const double *b_dev, double *x_dev, int max_iters, double *hist, int hist_cap, int *iters,
+                  double *seconds);
+    int amg_solve_dev(const double *b_dev, double *x_dev, int iterations, double *hist, int hist_cap, int *ncycles);
+
+    // stepwise CG / AMG-PCG (bench: time exactly k iterations)
+    int pcg_init(const double *b_dev, double *x_dev, bool precond);
+    int pcg_steps(int nsteps, int *done);
+    int krylov_hist(double *hist, int hist_cap);  // copies the residual history, returns iterations so far
+    double krylov_residual() const { return ks_.r1; }
+
+    // operator-level (device pointers)
+    void op_spmv(int l, const double *x, double *y);
+    void op_jacobi(int l, const double *b, double *x, double *tmp, int sweeps, bool x_is_zero);  // result in x
+    void op_residual(int l, const double *b, const double *x, double *r);
+    double op_resnorm(int l, const double *b, const double *x);
+    void op_restrict(int l, const double *r, double *bc);
+    void op_prolong(int l, const double *xc, double *xf);
+    void op_coarse(const double *b, double *x);
+    double op_dot(int n, const double *x, const double *y);
+
+    // device memory helpers
+    void *dalloc(size_t bytes);
+    void dfree(void *p);
+    bool check(hipError_t e, const char *what);
+    std::string error;
+
+    ProfileData prof;
+    double setup_seconds = 0.0;
+
+private:
+    // one V(nu,nu) cycle: rhs b0 (device, read-only), solution accumulates in lev_[0].x.
+    // x0_zero: the initial guess of level 0 is zero (preconditioner use).
+    // dot_partial: when non-null the last post-sweep also leaves partial sums of x.b there.
+    void vcycle(const double *b0, bool x0_zero, double *dot_partial, int *dot_nblk);
+    void smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, double *dot_partial, int *dot_nblk);
+    double read_scalar(int slot);
+    double read_hist(int it);
+
+    int pcg(const double *b, double *x, int max_iters, double *hist, int hist_cap, int *iters, bool precond);
+    int bicg(const double *b, double *x, int max_iters, double *hist, int hist_cap, int *iters, bool precond);
+
+    KrylovState ks_;
+    HostCsr A0_;
+    HostHierarchy H_;
+    sparsh_params prm_{};
+    std::vector<DevLevel> lev_;
+    double *coarse_inv_ = nullptr;
+    int nL_ = 0;
+    hipStream_t st_ = nullptr;
+    bool ready_ = false;
+    bool host_ready_ = false;
+    int device_ = 0;
+
+    // workspace
+    double *scal_ = nullptr;      // S_COUNT device scalars
+    double *part0_ = nullptr, *part1_ = nullptr;
+    int part_cap_ = 0;
+    double *hist_dev_ = nullptr;
+    int hist_cap_dev_ = 0;
+    double *pinned_ = nullptr;    // host-pinned staging for scalar read-back
+    std::vector<double *> work_;  // level-0 work vectors of the Krylov loops
+    std::vector<void *> allocs_;
+};
+
+}  // namespace sparsh

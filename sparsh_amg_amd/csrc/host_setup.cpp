@@ -1,0 +1,567 @@
+// host_setup.cpp -- AMG setup on the host without MKL/PARDISO.
+//
+// Behaviour follows the reference's setup (file:line relative to the reference tree):
+//   hierarchy loop            src/AMG_phases.cpp:35-90
+//   HEM pairwise aggregation  src/AMG_coarsening.cpp:14-97
+//   Beck C/F interpolation    src/AMG_coarsening.cpp:269-339
+//   Galerkin product P^T A P  src/AMG_cycle_utilities.cpp:126-146 (2x mkl_sparse_spmm + order)
+//   coarse factorisation      src/AMG_coarse_level_solver.cpp:9-62 (PARDISO phase 12)
+// Implementation is new: OpenMP row-parallel products with per-thread dense accumulators, an
+// aggregation-specialised Galerkin product, and RCM + banded LU producing the explicit
+// inverse the device applies as one GEMV per V-cycle.
+#include "host_setup.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <omp.h>
+
+namespace sparsh {
+
+namespace {
+
+double wall()
+{
+    using clk = std::chrono::steady_clock;
+    return std::chrono::duration<double>(clk::now().time_since_epoch()).count();
+}
+
+// exclusive prefix sum in place over counts stored at [1..n]
+void prefix(std::vector<int> &rp)
+{
+    for (size_t i = 1; i < rp.size(); ++i) rp[i] += rp[i - 1];
+}
+
+}  // namespace
+
+std::vector<double> extract_diagonal(const HostCsr &A)
+{
+    std::vector<double> d((size_t)A.nrow, 0.0);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < A.nrow; ++i) {
+        for (int j = A.rowptr[i]; j < A.rowptr[i + 1]; ++j) {
+            if (A.col[j] == i) {
+                d[i] = A.val[j];
+                break;
+            }
+        }
+    }
+    return d;
+}
+
+// Pairwise heavy-edge matching.  Rows are visited forward on even levels and backward on odd
+// levels; a free row grabs its free neighbour of strictly largest |a_ij| (first such in column
+// order); aggregates are numbered in visiting order, leftover rows become singletons numbered
+// afterwards in ascending row order.
+HostCsr hem_prolongator(const HostCsr &A, int level)
+{
+    const int n = A.nrow;
+    HostCsr P;
+    P.nrow = n;
+    P.rp_store.resize((size_t)n + 1);
+    P.col_store.assign((size_t)n, -1);
+    P.val_store.assign((size_t)n, 1.0);
+    std::iota(P.rp_store.begin(), P.rp_store.end(), 0);
+    int *agg = P.col_store.data();
+    int next = 0;
+    const bool fwd = (level % 2 == 0);
+    for (int t = 0; t < n; ++t) {
+        const int i = fwd ? t : n - 1 - t;
+        if (agg[i] != -1) continue;
+        int mate = -1;
+        double best = 0.0;
+        for (int j = A.rowptr[i]; j < A.rowptr[i + 1]; ++j) {
+            const int c = A.col[j];
+            const double w = std::fabs(A.val[j]);
+            if (c != i && agg[c] == -1 && w > best) {
+                best = w;
+                mate = c;
+            }
+        }
+        if (mate >= 0) {
+            agg[i] = next;
+            agg[mate] = next;
+            ++next;
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        if (agg[i] == -1) agg[i] = next++;
+    P.ncol = next;
+    P.adopt();
+    return P;
+}
+
+// Beck's greedy C/F split: walking rows in order, an undecided row becomes a C point and
+// decrements the counter of every row it touches; F rows (negative counter) interpolate from
+// their C neighbours with the uniform weight 1/|counter|; C rows inject.
+HostCsr beck_prolongator(const HostCsr &A)
+{
+    const int n = A.nrow;
+    std::vector<int> tag((size_t)n, 0);
+    int ncoarse = 0;
+    for (int i = 0; i < n; ++i) {
+        if (tag[i] != 0) continue;
+        for (int j = A.rowptr[i]; j < A.rowptr[i + 1]; ++j) tag[A.col[j]] -= 1;
+        tag[i] = ++ncoarse;
+    }
+    HostCsr P;
+    P.nrow = n;
+    P.ncol = ncoarse;
+    P.rp_store.assign((size_t)n + 1, 0);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        int cnt = 0;
+        if (tag[i] > 0) {
+            cnt = 1;
+        } else if (tag[i] < 0) {
+            for (int j = A.rowptr[i]; j < A.rowptr[i + 1]; ++j) cnt += tag[A.col[j]] > 0;
+        }
+        P.rp_store[(size_t)i + 1] = cnt;
+    }
+    prefix(P.rp_store);
+    P.col_store.resize((size_t)P.rp_store[n]);
+    P.val_store.resize((size_t)P.rp_store[n]);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        int q = P.rp_store[i];
+        if (tag[i] > 0) {
+            P.col_store[q] = tag[i] - 1;
+            P.val_store[q] = 1.0;
+        } else if (tag[i] < 0) {
+            const double w = 1 / std::fabs((double)tag[i]);
+            const int s = q;
+            for (int j = A.rowptr[i]; j < A.rowptr[i + 1]; ++j) {
+                const int k = A.col[j];
+                if (tag[k] > 0) {
+                    P.col_store[q] = tag[k] - 1;
+                    P.val_store[q] = w;
+                    ++q;
+                }
+            }
+            // sorted columns (the reference orders P through mkl_sparse_order); weights are equal
+            std::sort(P.col_store.begin() + s, P.col_store.begin() + q);
+        }
+    }
+    P.adopt();
+    return P;
+}
+
+// Explicit transpose; within each output row the entries keep ascending source-row order.
+HostCsr transpose(const HostCsr &A)
+{
+    const int nnz = A.nnz();
+    HostCsr T;
+    T.nrow = A.ncol;
+    T.ncol = A.nrow;
+    T.rp_store.assign((size_t)A.ncol + 1, 0);
+    for (int j = 0; j < nnz; ++j) T.rp_store[(size_t)A.col[j] + 1]++;
+    prefix(T.rp_store);
+    T.col_store.resize((size_t)nnz);
+    T.val_store.resize((size_t)nnz);
+    std::vector<int> cur(T.rp_store.begin(), T.rp_store.end() - 1);
+    for (int i = 0; i < A.nrow; ++i) {
+        for (int j = A.rowptr[i]; j < A.rowptr[i + 1]; ++j) {
+            const int q = cur[A.col[j]]++;
+            T.col_store[q] = i;
+            T.val_store[q] = A.val[j];
+        }
+    }
+    T.adopt();
+    return T;
+}
+
+namespace {
+
+// C = A * B, row-parallel with a dense accumulator per thread; all structural entries kept
+// (also exact zeros, as MKL's spmm does: SURVEY Q11); columns sorted.
+HostCsr spgemm(const HostCsr &A, const HostCsr &B)
+{
+    const int n = A.nrow, m = B.ncol;
+    HostCsr C;
+    C.nrow = n;
+    C.ncol = m;
+    C.rp_store.assign((size_t)n + 1, 0);
+#pragma omp parallel
+    {
+        std::vector<int> mark((size_t)m, -1);
+#pragma omp for schedule(static)
+        for (int i = 0; i < n; ++i) {
+            int cnt = 0;
+            for (int ja = A.rowptr[i]; ja < A.rowptr[i + 1]; ++ja) {
+                const int k = A.col[ja];
+                for (int jb = B.rowptr[k]; jb < B.rowptr[k + 1]; ++jb) {
+                    const int c = B.col[jb];
+                    if (mark[c] != i) {
+                        mark[c] = i;
+                        ++cnt;
+                    }
+                }
+            }
+            C.rp_store[(size_t)i + 1] = cnt;
+        }
+    }
+    prefix(C.rp_store);
+    C.col_store.resize((size_t)C.rp_store[n]);
+    C.val_store.resize((size_t)C.rp_store[n]);
+#pragma omp parallel
+    {
+        std::vector<int> mark((size_t)m, -1);
+        std::vector<double> acc((size_t)m, 0.0);
+#pragma omp for schedule(static)
+        for (int i = 0; i < n; ++i) {
+            const int s = C.rp_store[i];
+            int q = s;
+            for (int ja = A.rowptr[i]; ja < A.rowptr[i + 1]; ++ja) {
+                const int k = A.col[ja];
+                const double av = A.val[ja];
+                for (int jb = B.rowptr[k]; jb < B.rowptr[k + 1]; ++jb) {
+                    const int c = B.col[jb];
+                    const double t = av * B.val[jb];
+                    if (mark[c] != i) {
+                        mark[c] = i;
+                        C.col_store[q++] = c;
+                        acc[c] = t;
+                    } else {
+                        acc[c] += t;
+                    }
+                }
+            }
+            std::sort(C.col_store.begin() + s, C.col_store.begin() + q);
+            for (int j = s; j < q; ++j) C.val_store[j] = acc[C.col_store[j]];
+        }
+    }
+    C.adopt();
+    return C;
+}
+
+// Galerkin product for an aggregation prolongator (one unit entry per row):
+//   Ac[I][J] = sum_{i in agg I} ( sum_{j in agg J} a_ij )
+// evaluated in exactly the order of the two-product form P^T (A P): first the partial row of
+// A P for fine row i (entries added in column order), then fine rows added in ascending i.
+HostCsr galerkin_aggregation(const HostCsr &A, const HostCsr &P, const HostCsr &R)
+{
+    const int nc = P.ncol;
+    const int *agg = P.col;
+    HostCsr C;
+    C.nrow = nc;
+    C.ncol = nc;
+    C.rp_store.assign((size_t)nc + 1, 0);
+#pragma omp parallel
+    {
+        std::vector<int> mark((size_t)nc, -1);
+#pragma omp for schedule(static)
+        for (int I = 0; I < nc; ++I) {
+            int cnt = 0;
+            for (int t = R.rowptr[I]; t < R.rowptr[I + 1]; ++t) {
+                const int i = R.col[t];
+                for (int j = A.rowptr[i]; j < A.rowptr[i + 1]; ++j) {
+                    const int c = agg[A.col[j]];
+                    if (mark[c] != I) {
+                        mark[c] = I;
+                        ++cnt;
+                    }
+                }
+            }
+            C.rp_store[(size_t)I + 1] = cnt;
+        }
+    }
+    prefix(C.rp_store);
+    C.col_store.resize((size_t)C.rp_store[nc]);
+    C.val_store.resize((size_t)C.rp_store[nc]);
+#pragma omp parallel
+    {
+        std::vector<int> markI((size_t)nc, -1), markF((size_t)nc, -1);
+        std::vector<double> accI((size_t)nc, 0.0), accF((size_t)nc, 0.0);
+        std::vector<int> touched;
+#pragma omp for schedule(static)
+        for (int I = 0; I < nc; ++I) {
+            const int s = C.rp_store[I];
+            int q = s;
+            for (int t = R.rowptr[I]; t < R.rowptr[I + 1]; ++t) {
+                const int i = R.col[t];
+                touched.clear();
+                for (int j = A.rowptr[i]; j < A.rowptr[i + 1]; ++j) {  // row i of A*P
+                    const int c = agg[A.col[j]];
+                    const double v = A.val[j] * 1.0;
+                    if (markF[c] != i) {
+                        markF[c] = i;
+                        accF[c] = v;
+                        touched.push_back(c);
+                    } else {
+                        accF[c] += v;
+                    }
+                }
+                for (int c : touched) {  // P^T gathers the rows of A*P
+                    const double v = 1.0 * accF[c];
+                    if (markI[c] != I) {
+                        markI[c] = I;
+                        C.col_store[q++] = c;
+                        accI[c] = v;
+                    } else {
+                        accI[c] += v;
+                    }
+                }
+            }
+            std::sort(C.col_store.begin() + s, C.col_store.begin() + q);
+            for (int j = s; j < q; ++j) C.val_store[j] = accI[C.col_store[j]];
+        }
+    }
+    C.adopt();
+    return C;
+}
+
+}  // namespace
+
+HostCsr galerkin(const HostCsr &A, const HostCsr &P, const HostCsr &R, bool P_is_aggregation)
+{
+    if (P_is_aggregation) return galerkin_aggregation(A, P, R);
+    HostCsr AP = spgemm(A, P);
+    return spgemm(R, AP);
+}
+
+// ---------------------------------------------------------------------------------------
+// Coarse direct solver: reverse Cuthill-McKee + banded LU with partial pivoting, then the
+// explicit inverse column by column.  Replaces PARDISO (mtype 11) of the reference.
+
+namespace {
+
+std::vector<int> rcm(const HostCsr &A)
+{
+    const int n = A.nrow;
+    HostCsr T = transpose(A);
+    std::vector<std::vector<int>> adj((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        auto &a = adj[i];
+        for (int j = A.rowptr[i]; j < A.rowptr[i + 1]; ++j)
+            if (A.col[j] != i) a.push_back(A.col[j]);
+        for (int j = T.rowptr[i]; j < T.rowptr[i + 1]; ++j)
+            if (T.col[j] != i) a.push_back(T.col[j]);
+        std::sort(a.begin(), a.end());
+        a.erase(std::unique(a.begin(), a.end()), a.end());
+    }
+    std::vector<int> order;
+    order.reserve((size_t)n);
+    std::vector<int> state((size_t)n, 0), depth((size_t)n, 0), q;
+    auto bfs_far = [&](int start) {  // returns lowest-degree node of the deepest BFS level
+        q.assign(1, start);
+        state[start] = 2;
+        depth[start] = 0;
+        for (size_t h = 0; h < q.size(); ++h)
+            for (int w : adj[q[h]])
+                if (state[w] == 0) {
+                    state[w] = 2;
+                    depth[w] = depth[q[h]] + 1;
+                    q.push_back(w);
+                }
+        int far = q.back();
+        for (size_t k = q.size(); k-- > 0 && depth[q[k]] == depth[q.back()];)
+            if (adj[q[k]].size() < adj[far].size()) far = q[k];
+        for (int v : q) state[v] = 0;
+        return far;
+    };
+    for (int seed = 0; seed < n; ++seed) {
+        if (state[seed]) continue;
+        int start = seed;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int far = bfs_far(start);
+            if (far == start) break;
+            start = far;
+        }
+        size_t head = order.size();
+        order.push_back(start);
+        state[start] = 1;
+        while (head < order.size()) {
+            const int v = order[head++];
+            const size_t s = order.size();
+            for (int w : adj[v])
+                if (!state[w]) {
+                    state[w] = 1;
+                    order.push_back(w);
+                }
+            std::stable_sort(order.begin() + s, order.end(), [&](int a, int b) { return adj[a].size() < adj[b].size(); });
+        }
+    }
+    std::reverse(order.begin(), order.end());
+    return order;  // order[new] = old
+}
+
+struct BandLU {
+    int n = 0, kl = 0, ku = 0, W = 0;
+    std::vector<double> ab;  // row i: columns i-kl .. i+ku+kl
+    std::vector<int> piv, perm;
+    double &at(int i, int j) { return ab[(size_t)i * W + (size_t)(j - i + kl)]; }
+    double at(int i, int j) const { return ab[(size_t)i * W + (size_t)(j - i + kl)]; }
+};
+
+bool band_factor(const HostCsr &A, BandLU &F)
+{
+    const int n = A.nrow;
+    F.n = n;
+    F.perm = rcm(A);
+    std::vector<int> inv((size_t)n);
+    for (int i = 0; i < n; ++i) inv[F.perm[i]] = i;
+    int kl = 0, ku = 0;
+    for (int i = 0; i < n; ++i)
+        for (int j = A.rowptr[i]; j < A.rowptr[i + 1]; ++j) {
+            const int d = inv[i] - inv[A.col[j]];
+            kl = std::max(kl, d);
+            ku = std::max(ku, -d);
+        }
+    F.kl = kl;
+    F.ku = ku;
+    F.W = 2 * kl + ku + 1;
+    F.ab.assign((size_t)n * F.W, 0.0);
+    F.piv.resize((size_t)n);
+    for (int i = 0; i < n; ++i)
+        for (int j = A.rowptr[i]; j < A.rowptr[i + 1]; ++j) F.at(inv[i], inv[A.col[j]]) += A.val[j];
+    const int uw = kl + ku;
+    for (int k = 0; k < n; ++k) {
+        const int iend = std::min(k + kl, n - 1), jend = std::min(k + uw, n - 1);
+        int p = k;
+        double amax = std::fabs(F.at(k, k));
+        for (int i = k + 1; i <= iend; ++i) {
+            const double v = std::fabs(F.at(i, k));
+            if (v > amax) {
+                amax = v;
+                p = i;
+            }
+        }
+        F.piv[k] = p;
+        if (amax == 0.0) return false;
+        if (p != k)
+            for (int j = k; j <= jend; ++j) std::swap(F.at(k, j), F.at(p, j));
+        const double pv = F.at(k, k);
+        const double *rk = &F.at(k, k);
+        const int len = jend - k;
+#pragma omp parallel for schedule(static) if ((long)(iend - k) * len > 40000)
+        for (int i = k + 1; i <= iend; ++i) {
+            double *ri = &F.at(i, k);
+            const double l = ri[0] / pv;
+            ri[0] = l;
+            for (int j = 1; j <= len; ++j) ri[j] -= l * rk[j];
+        }
+    }
+    return true;
+}
+
+// solve for the unit vector e_c (permuted numbering); the forward sweep may start at row
+// kstart <= c when no interchange before kstart touches row c; y is scratch/out (permuted)
+void band_solve_unit(const BandLU &F, int c, int kstart, double *y)
+{
+    const int n = F.n, kl = F.kl, uw = F.kl + F.ku;
+    std::fill(y, y + n, 0.0);
+    y[c] = 1.0;
+    for (int k = kstart; k < n; ++k) {
+        const int p = F.piv[k];
+        if (p != k) std::swap(y[k], y[p]);
+        const double yk = y[k];
+        if (yk == 0.0) continue;
+        const int iend = std::min(k + kl, n - 1);
+        for (int i = k + 1; i <= iend; ++i) y[i] -= F.at(i, k) * yk;
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        const int jend = std::min(i + uw, n - 1);
+        double s = y[i];
+        const double *ri = &F.ab[(size_t)i * F.W + (size_t)kl];
+        for (int j = 1; j <= jend - i; ++j) s -= ri[j] * y[i + j];
+        y[i] = s / ri[0];
+    }
+}
+
+}  // namespace
+
+bool sparse_inverse(const HostCsr &A, std::vector<double> &inv)
+{
+    const int n = A.nrow;
+    BandLU F;
+    if (!band_factor(A, F)) return false;
+    inv.assign((size_t)n * n, 0.0);
+    // A unit vector at row c is untouched by the interchanges of steps k < c when none of
+    // them references a row >= c; then the forward sweep can start at row c.
+    std::vector<char> safe((size_t)n, 1);
+    {
+        int maxp = -1;
+        for (int c = 0; c < n; ++c) {
+            safe[c] = (maxp < c);
+            maxp = std::max(maxp, F.piv[c]);
+        }
+    }
+#pragma omp parallel
+    {
+        std::vector<double> y((size_t)n);
+#pragma omp for schedule(dynamic, 16)
+        for (int c = 0; c < n; ++c) {
+            band_solve_unit(F, c, safe[c] ? c : 0, y.data());
+            // x_perm = y ; column perm[c] of A^{-1}: inv[perm[i]][perm[c]] = y[i]
+            const int oc = F.perm[c];
+            for (int i = 0; i < n; ++i) inv[(size_t)F.perm[i] * n + oc] = y[i];
+        }
+    }
+    return true;
+}
+
+bool build_hierarchy(const HostCsr &A0, const SetupParams &prm, HostHierarchy &H)
+{
+    const double t0 = wall();
+    if (prm.host_threads > 0) omp_set_num_threads(prm.host_threads);
+    H.levels.clear();
+    H.levels.emplace_back();
+    H.levels[0].A = HostCsr::alias(A0.nrow, A0.ncol, A0.rowptr, A0.col, A0.val);
+    H.levels[0].diag = extract_diagonal(H.levels[0].A);
+    H.extended = false;
+    int l = 0;
+    if (prm.print) std::printf("AMG Setup Phase Details Jacobi smoother\n");
+    for (;;) {
+        const int n = H.levels[l].A.nrow;
+        const bool within_ref = l < prm.max_levels - 1;
+        if (!(n > prm.limit_upper && (within_ref || n > prm.coarse_limit))) break;
+        if (!within_ref) H.extended = true;
+        if (prm.print) std::printf("Level %d:\t%d\n", l, n);
+        HostLevel &L = H.levels[l];
+        if (prm.coarsening == 1) {
+            L.P = beck_prolongator(L.A);
+            L.P_is_aggregation = false;
+        } else {
+            L.P = hem_prolongator(L.A, l);
+            L.P_is_aggregation = true;
+        }
+        L.R = transpose(L.P);
+        if (L.P.ncol >= n) {  // no coarsening progress
+            L.P = HostCsr();
+            L.R = HostCsr();
+            break;
+        }
+        HostLevel next;
+        next.A = galerkin(L.A, L.P, L.R, L.P_is_aggregation);
+        next.diag = extract_diagonal(next.A);
+        H.levels.push_back(std::move(next));
+        // vectors moved: re-point views
+        for (auto &lv : H.levels) {
+            if (!lv.A.rp_store.empty()) lv.A.adopt();
+            if (!lv.P.rp_store.empty()) lv.P.adopt();
+            if (!lv.R.rp_store.empty()) lv.R.adopt();
+        }
+        ++l;
+        if (H.levels[l].A.nrow < prm.limit_lower) break;
+    }
+    if (prm.print) std::printf("Level %d:\t%d\n", l, H.levels[l].A.nrow);
+    const HostCsr &AL = H.levels[l].A;
+    H.nL = AL.nrow;
+    if (H.nL > std::max(prm.coarse_limit, prm.limit_upper) * 2) {
+        H.error = "coarsest level has " + std::to_string(H.nL) + " rows: too large for the device direct solve (coarsening stalled)";
+        return false;
+    }
+    if (H.extended && prm.print)
+        std::printf("note: hierarchy extended past %d levels (coarsest level would exceed coarse_limit=%d)\n", prm.max_levels, prm.coarse_limit);
+    if (!sparse_inverse(AL, H.coarse_inverse)) {
+        H.error = "coarsest-level matrix is singular";
+        return false;
+    }
+    H.seconds = wall() - t0;
+    return true;
+}
+
+}  // namespace sparsh

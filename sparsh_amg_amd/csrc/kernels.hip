@@ -1,0 +1,526 @@
+// kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, CDNA4): the AMG solve-phase
+// operators.  Wave = 64 lanes, workgroup = 256 threads (one wave per SIMD).  All kernels are
+// HBM-bandwidth bound (SpMV: 2 flop per 12 B); there is no MFMA here on purpose.
+//
+// Arithmetic contract (parity with the reference's CPU path, built with -ffp-contract=off):
+//   * a row sum adds the products a_ij*x_j one by one in stored column order, each product
+//     rounded before the add -- the order of a scalar CPU loop over the CSR row;
+//   * Jacobi: h = b - s ; x_new = x + (omega*h)/d  (src/AMG_smoothers.cpp:62-72);
+//   * reductions are two-stage (per-workgroup partial -> one finalize workgroup), fixed tree
+//     order: bitwise reproducible run to run, no float atomics.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace sparsh {
+
+namespace {
+
+// ------------------------------------------------------------------ helpers
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;  // valid in lane 0
+}
+
+// sum over the workgroup; result valid in thread 0.  red must hold kBlock/64 doubles.
+__device__ __forceinline__ double block_sum(double v, double *red)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < kBlock / 64; ++k) s += red[k];
+    }
+    return s;
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD, MI355X
+// microarch guide).  Give each XCD one contiguous range of row blocks so the x-vector lines
+// its neighbouring row blocks share stay in that XCD's 4 MiB L2.  Placement affects speed only.
+__device__ __forceinline__ int xcd_remap(int b, int nblk)
+{
+    const int chunk = (nblk + 7) >> 3;
+    return (b & 7) * chunk + (b >> 3);
+}
+
+template <bool NT>
+__device__ __forceinline__ double ld_stream(const double *p)
+{
+    if constexpr (NT)
+        return __builtin_nontemporal_load(p);
+    else
+        return *p;
+}
+template <bool NT>
+__device__ __forceinline__ int ld_stream(const int *p)
+{
+    if constexpr (NT)
+        return __builtin_nontemporal_load(p);
+    else
+        return *p;
+}
+
+// ------------------------------------------------------------------ CSR-stream kernel
+//
+// One workgroup owns a run of consecutive rows whose nnz fit the LDS product buffer.
+// Phase 1: the 256 threads walk the run's nnz range with unit stride -- val/col reads are
+// fully coalesced -- gather x[col] (L1/L2-served for banded matrices) and park the rounded
+// products in LDS.  Phase 2: one thread per row adds its products in stored order.
+// A row longer than the buffer is handled by a whole workgroup with a strided partial sum.
+template <int OP, bool NT>
+__global__ __launch_bounds__(kBlock) void csr_stream_kernel(const int *__restrict__ rowblk, int nblk,
+                                                             const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                             const double *__restrict__ val, CsrArgs a)
+{
+    __shared__ double prod[kStreamNnz];
+    __shared__ double red[kBlock / 64];
+    const int bid = xcd_remap(blockIdx.x, nblk);
+    if (bid >= nblk) return;  // whole workgroup leaves together
+    const int tid = threadIdx.x;
+    const int r0 = rowblk[bid], r1 = rowblk[bid + 1];
+    const int nrows = r1 - r0;
+    const int j0 = rowptr[r0], j1 = rowptr[r1];
+    const double *__restrict__ x = a.x;
+
+    double sum = 0.0;
+    int row = -1;
+    if (nrows == 1 && j1 - j0 > kStreamNnz) {
+        double part = 0.0;
+        for (int j = j0 + tid; j < j1; j += kBlock) part += ld_stream<NT>(val + j) * x[ld_stream<NT>(col + j)];
+        part = block_sum(part, red);
+        __syncthreads();
+        if (tid == 0) {
+            sum = part;
+            row = r0;
+        }
+    } else {
+        for (int j = j0 + tid; j < j1; j += kBlock) prod[j - j0] = ld_stream<NT>(val + j) * x[ld_stream<NT>(col + j)];
+        __syncthreads();
+        if (tid < nrows) {
+            row = r0 + tid;
+            const int s = rowptr[row] - j0, e = rowptr[row + 1] - j0;
+            for (int k = s; k < e; ++k) sum += prod[k];
+        }
+    }
+
+    double acc = 0.0;
+    if (row >= 0) {
+        if constexpr (OP == OP_SPMV) {
+            a.y[row] = sum;
+        } else if constexpr (OP == OP_RESID) {
+            a.y[row] = 1.0 * a.b[row] + (-1.0) * sum;
+        } else if constexpr (OP == OP_JACOBI || OP == OP_JACOBI_DOT) {
+            const double bi = a.b[row];
+            const double h = 1.0 * bi + (-1.0) * sum;
+            const double xn = x[row] + a.omega * h / a.d[row];
+            a.y[row] = xn;
+            if constexpr (OP == OP_JACOBI_DOT) acc = xn * bi;
+        } else if constexpr (OP == OP_ADD) {
+            a.y[row] = sum + a.y[row];
+        } else if constexpr (OP == OP_SPMV_DOT) {
+            a.y[row] = sum;
+            acc = x[row] * sum;
+        } else if constexpr (OP == OP_RESNORM) {
+            const double h = sum + (-1.0) * a.b[row];
+            acc = h * h;
+        }
+    }
+    if constexpr (OP == OP_SPMV_DOT || OP == OP_RESNORM || OP == OP_JACOBI_DOT) {
+        __syncthreads();
+        const double t = block_sum(acc, red);
+        if (tid == 0) a.partial[bid] = t;
+    }
+}
+
+template <int OP>
+void launch_csr_op(const DevCsr &A, const CsrArgs &a, bool fine, hipStream_t st)
+{
+    if (A.nblk <= 0) return;
+    const int grid = ((A.nblk + 7) >> 3) << 3;
+    if (fine)
+        hipLaunchKernelGGL((csr_stream_kernel<OP, true>), dim3(grid), dim3(kBlock), 0, st, A.rowblk, A.nblk, A.rowptr, A.col, A.val, a);
+    else
+        hipLaunchKernelGGL((csr_stream_kernel<OP, false>), dim3(grid), dim3(kBlock), 0, st, A.rowblk, A.nblk, A.rowptr, A.col, A.val, a);
+}
+
+// ------------------------------------------------------------------ elementwise
+
+constexpr int kEwGridMax = 2048;  // grid-stride: ~8 workgroups per CU
+
+inline int ew_grid(int n)
+{
+    int g = (n + kBlock * 2 - 1) / (kBlock * 2);
+    if (g < 1) g = 1;
+    return g > kEwGridMax ? kEwGridMax : g;
+}
+
+__global__ __launch_bounds__(kBlock) void jacobi_zero_kernel(int n, const double *__restrict__ b, const double *__restrict__ d,
+                                                              double omega, double *__restrict__ x)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        // x = 0 + omega*(b - 0)/d ; (b - 0) and (0 + t) are exact
+        x[i] = omega * b[i] / d[i];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void prolong_agg_kernel(int n, const int *__restrict__ agg, const double *__restrict__ xc,
+                                                              double *__restrict__ xf)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) xf[i] = 1.0 * xc[agg[i]] + xf[i];
+}
+
+__global__ __launch_bounds__(kBlock) void fill_kernel(int n, double v, double *__restrict__ x)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) x[i] = v;
+}
+
+__global__ __launch_bounds__(kBlock) void copy_kernel(int n, const double *__restrict__ x, double *__restrict__ y)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) y[i] = x[i];
+}
+
+__global__ __launch_bounds__(kBlock) void axpby_kernel(int n, double a, const double *__restrict__ x, double b, double *__restrict__ y)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) y[i] = a * x[i] + b * y[i];
+}
+
+__global__ __launch_bounds__(kBlock) void dot_kernel(int n, const double *__restrict__ x, const double *__restrict__ y,
+                                                      double *__restrict__ partial)
+{
+    __shared__ double red[kBlock / 64];
+    double acc = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) acc += x[i] * y[i];
+    const double t = block_sum(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(kBlock) void dot2_kernel(int n, const double *__restrict__ a, const double *__restrict__ b,
+                                                       const double *__restrict__ c, const double *__restrict__ d,
+                                                       double *__restrict__ p0, double *__restrict__ p1)
+{
+    __shared__ double red[kBlock / 64];
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        s0 += a[i] * b[i];
+        s1 += c[i] * d[i];
+    }
+    const double t0 = block_sum(s0, red);
+    __syncthreads();
+    const double t1 = block_sum(s1, red);
+    if (threadIdx.x == 0) {
+        p0[blockIdx.x] = t0;
+        p1[blockIdx.x] = t1;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void cg_update_kernel(int n, const double *__restrict__ scal, const double *__restrict__ p,
+                                                            const double *__restrict__ Ap, double *__restrict__ x,
+                                                            double *__restrict__ r, double *__restrict__ partial)
+{
+    __shared__ double red[kBlock / 64];
+    const double alpha = scal[S_ALPHA], nalpha = scal[S_NALPHA];
+    double acc = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        x[i] = x[i] + alpha * p[i];        // cblas_daxpy(alpha, p, x)
+        const double ri = r[i] + nalpha * Ap[i];  // cblas_daxpy(-alpha, Ap, r)
+        r[i] = ri;
+        acc += ri * ri;
+    }
+    const double t = block_sum(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(kBlock) void p_update_kernel(int n, const double *__restrict__ scal, const double *__restrict__ z,
+                                                           double *__restrict__ p)
+{
+    const double beta = scal[S_BETA];
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) p[i] = 1.0 * z[i] + beta * p[i];
+}
+
+__global__ __launch_bounds__(kBlock) void bicg_s_kernel(int n, const double *__restrict__ scal, const double *__restrict__ r,
+                                                         const double *__restrict__ Ap, double *__restrict__ s)
+{
+    const double alpha = scal[S_ALPHA];
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) s[i] = r[i] - alpha * Ap[i];
+}
+
+__global__ __launch_bounds__(kBlock) void bicg_xr_kernel(int n, const double *__restrict__ scal, const double *__restrict__ p1,
+                                                          const double *__restrict__ s1, const double *__restrict__ s,
+                                                          const double *__restrict__ As, const double *__restrict__ r0,
+                                                          double *__restrict__ x, double *__restrict__ r, double *__restrict__ q0,
+                                                          double *__restrict__ q1)
+{
+    __shared__ double red[kBlock / 64];
+    const double alpha = scal[S_ALPHA], omega1 = scal[S_OMEGA1];
+    double a0 = 0.0, a1 = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        x[i] = x[i] + alpha * p1[i] + omega1 * s1[i];
+        const double ri = s[i] - omega1 * As[i];
+        r[i] = ri;
+        a0 += ri * r0[i];
+        a1 += ri * ri;
+    }
+    const double t0 = block_sum(a0, red);
+    __syncthreads();
+    const double t1 = block_sum(a1, red);
+    if (threadIdx.x == 0) {
+        q0[blockIdx.x] = t0;
+        q1[blockIdx.x] = t1;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void bicg_p_kernel(int n, const double *__restrict__ scal, const double *__restrict__ r,
+                                                         const double *__restrict__ Ap, double *__restrict__ p)
+{
+    const double beta = scal[S_BETA], omega1 = scal[S_OMEGA1];
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) p[i] = r[i] + beta * (p[i] - omega1 * Ap[i]);
+}
+
+// ------------------------------------------------------------------ coarse GEMV
+// x = M b, M row-major n x n (explicit inverse of the coarsest operator): one wave per row,
+// lanes stride the row with 16-byte loads; b (<= 64 KiB) is served by L1/L2.
+__global__ __launch_bounds__(kBlock) void gemv_kernel(int n, const double *__restrict__ M, const double *__restrict__ b,
+                                                       double *__restrict__ x)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (row >= n) return;  // whole wave leaves
+    const double *__restrict__ m = M + (size_t)row * n;
+    double acc = 0.0;
+    const int n2 = n & ~1;
+    if ((((size_t)row * n) & 1) == 0) {  // row start 16-byte aligned
+        for (int j = lane * 2; j < n2; j += 128) {
+            const double2 mv = *reinterpret_cast<const double2 *>(m + j);
+            const double2 bv = *reinterpret_cast<const double2 *>(b + j);
+            acc += mv.x * bv.x;
+            acc += mv.y * bv.y;
+        }
+    } else {
+        for (int j = lane * 2; j < n2; j += 128) {
+            acc += m[j] * b[j];
+            acc += m[j + 1] * b[j + 1];
+        }
+    }
+    if (lane == 0 && n2 < n) acc += m[n2] * b[n2];
+    acc = wave_sum(acc);
+    if (lane == 0) x[row] = acc;
+}
+
+// ------------------------------------------------------------------ finalize
+// One workgroup adds the per-workgroup partials in a fixed order and updates the scalar slots.
+constexpr int kFinBlock = 1024;
+
+__global__ __launch_bounds__(kFinBlock) void finalize_kernel(int code, const double *__restrict__ p0, const double *__restrict__ p1,
+                                                              int nblk, double *__restrict__ scal, int slot_a,
+                                                              double *__restrict__ hist, int it)
+{
+    __shared__ double red0[kFinBlock / 64], red1[kFinBlock / 64];
+    double a0 = 0.0, a1 = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += kFinBlock) {
+        a0 += p0[i];
+        if (p1) a1 += p1[i];
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        red0[w] = a0;
+        red1[w] = a1;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < kFinBlock / 64; ++k) {
+        s0 += red0[k];
+        s1 += red1[k];
+    }
+    switch (code) {
+    case FIN_STORE: scal[slot_a] = s0; break;
+    case FIN_SQRT: {
+        const double v = sqrt(s0);
+        scal[slot_a] = v;
+        if (hist) hist[it] = v;
+    } break;
+    case FIN_PCG_ALPHA: {
+        scal[S_PAP] = s0;
+        const double alpha = scal[S_RZ] / s0;
+        scal[S_ALPHA] = alpha;
+        scal[S_NALPHA] = -alpha;
+    } break;
+    case FIN_PCG_BETA: {
+        scal[S_ZR] = s0;
+        scal[S_BETA] = s0 / scal[S_RZ];
+        scal[S_RZ] = s0;
+    } break;
+    case FIN_CG_ALPHA: {
+        scal[S_PAP] = s0;
+        const double alpha = scal[S_RR] / s0;
+        scal[S_ALPHA] = alpha;
+        scal[S_NALPHA] = -alpha;
+    } break;
+    case FIN_CG_BETA: {
+        const double s = scal[S_RR];
+        const double beta = s0 / s;
+        scal[S_BETA] = beta;
+        const double res = sqrt(s * beta);
+        scal[S_RES] = res;
+        scal[S_RR] = s0;
+        if (hist) hist[it] = res;
+    } break;
+    case FIN_BICG_ALPHA: {
+        scal[S_ALPHA1] = s0;
+        scal[S_APR0] = s1;
+        scal[S_ALPHA] = s0 / s1;
+    } break;
+    case FIN_BICG_OMEGA: {
+        scal[S_ASS] = s0;
+        scal[S_ASAS] = s1;
+        scal[S_OMEGA1] = s0 / s1;
+    } break;
+    case FIN_BICG_BETA: {
+        double beta = s0 / scal[S_ALPHA1];
+        beta = beta * (scal[S_ALPHA] / scal[S_OMEGA1]);
+        scal[S_BETA] = beta;
+        scal[S_RR0] = s0;
+        const double res = sqrt(s1);
+        scal[S_RES] = res;
+        if (hist) hist[it] = res;
+    } break;
+    default: break;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ host launchers
+
+int build_rowblocks(int nrow, const int *rowptr, int *out)
+{
+    int nb = 0;
+    out[0] = 0;
+    int r = 0;
+    while (r < nrow) {
+        int rows = 0;
+        long nnz = 0;
+        while (r + rows < nrow && rows < kBlock) {
+            const long len = (long)rowptr[r + rows + 1] - rowptr[r + rows];
+            if (rows > 0 && nnz + len > kStreamNnz) break;
+            nnz += len;
+            ++rows;
+            if (nnz > kStreamNnz) break;  // single long row: own block
+        }
+        r += rows;
+        out[++nb] = r;
+    }
+    return nb;
+}
+
+void launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool fine, hipStream_t st)
+{
+    switch (op) {
+    case OP_SPMV: launch_csr_op<OP_SPMV>(A, a, fine, st); break;
+    case OP_RESID: launch_csr_op<OP_RESID>(A, a, fine, st); break;
+    case OP_JACOBI: launch_csr_op<OP_JACOBI>(A, a, fine, st); break;
+    case OP_ADD: launch_csr_op<OP_ADD>(A, a, fine, st); break;
+    case OP_SPMV_DOT: launch_csr_op<OP_SPMV_DOT>(A, a, fine, st); break;
+    case OP_RESNORM: launch_csr_op<OP_RESNORM>(A, a, fine, st); break;
+    case OP_JACOBI_DOT: launch_csr_op<OP_JACOBI_DOT>(A, a, fine, st); break;
+    }
+}
+
+void launch_jacobi_zero(int n, const double *b, const double *d, double omega, double *x, hipStream_t st)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(jacobi_zero_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, st, n, b, d, omega, x);
+}
+
+void launch_prolong_agg(int n, const int *agg, const double *xc, double *xf, hipStream_t st)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(prolong_agg_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, st, n, agg, xc, xf);
+}
+
+void launch_gemv(int n, const double *M, const double *b, double *x, hipStream_t st)
+{
+    if (n <= 0) return;
+    const int rows_per_blk = kBlock / 64;
+    hipLaunchKernelGGL(gemv_kernel, dim3((n + rows_per_blk - 1) / rows_per_blk), dim3(kBlock), 0, st, n, M, b, x);
+}
+
+void launch_fill(int n, double v, double *x, hipStream_t st)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, st, n, v, x);
+}
+
+void launch_copy(int n, const double *x, double *y, hipStream_t st)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(copy_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, st, n, x, y);
+}
+
+void launch_axpby(int n, double a, const double *x, double b, double *y, hipStream_t st)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, st, n, a, x, b, y);
+}
+
+void launch_dot(int n, const double *x, const double *y, double *partial, int *nblk, hipStream_t st)
+{
+    const int g = ew_grid(n);
+    *nblk = g;
+    hipLaunchKernelGGL(dot_kernel, dim3(g), dim3(kBlock), 0, st, n, x, y, partial);
+}
+
+void launch_dot2(int n, const double *a, const double *b, const double *c, const double *d, double *partial0, double *partial1,
+                 int *nblk, hipStream_t st)
+{
+    const int g = ew_grid(n);
+    *nblk = g;
+    hipLaunchKernelGGL(dot2_kernel, dim3(g), dim3(kBlock), 0, st, n, a, b, c, d, partial0, partial1);
+}
+
+void launch_finalize(Fin code, const double *partial0, const double *partial1, int nblk, double *scal, int slot_a, double *hist,
+                     int it, hipStream_t st)
+{
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kFinBlock), 0, st, (int)code, partial0, partial1, nblk, scal, slot_a, hist, it);
+}
+
+void launch_cg_update(int n, const double *scal, const double *p, const double *Ap, double *x, double *r, double *partial,
+                      int *nblk, hipStream_t st)
+{
+    const int g = ew_grid(n);
+    *nblk = g;
+    hipLaunchKernelGGL(cg_update_kernel, dim3(g), dim3(kBlock), 0, st, n, scal, p, Ap, x, r, partial);
+}
+
+void launch_p_update(int n, const double *scal, const double *z, double *p, hipStream_t st)
+{
+    hipLaunchKernelGGL(p_update_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, st, n, scal, z, p);
+}
+
+void launch_bicg_s(int n, const double *scal, const double *r, const double *Ap, double *s, hipStream_t st)
+{
+    hipLaunchKernelGGL(bicg_s_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, st, n, scal, r, Ap, s);
+}
+
+void launch_bicg_xr(int n, const double *scal, const double *p1, const double *s1, const double *s, const double *As,
+                    const double *r0, double *x, double *r, double *partial0, double *partial1, int *nblk, hipStream_t st)
+{
+    const int g = ew_grid(n);
+    *nblk = g;
+    hipLaunchKernelGGL(bicg_xr_kernel, dim3(g), dim3(kBlock), 0, st, n, scal, p1, s1, s, As, r0, x, r, partial0, partial1);
+}
+
+void launch_bicg_p(int n, const double *scal, const double *r, const double *Ap, double *p, hipStream_t st)
+{
+    hipLaunchKernelGGL(bicg_p_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, st, n, scal, r, Ap, p);
+}
+
+}  // namespace sparsh

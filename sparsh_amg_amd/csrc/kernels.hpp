@@ -1,0 +1,104 @@
+// kernels.hpp -- launch interface of the hand-written gfx950 kernels (kernels.hip).
+// Everything here works on device pointers and enqueues on the given HIP stream; nothing
+// allocates, synchronises or touches the host (graph-capture safe).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+namespace sparsh {
+
+// Device CSR + the row-block schedule of the CSR-stream kernels.
+struct DevCsr {
+    int nrow = 0, ncol = 0, nnz = 0;
+    int *rowptr = nullptr;
+    int *col = nullptr;
+    double *val = nullptr;
+    // row blocks: block k owns rows [rowblk[k], rowblk[k+1]); nnz of a block <= kStreamNnz unless
+    // it is a single long row
+    int *rowblk = nullptr;
+    int nblk = 0;
+};
+
+constexpr int kBlock = 256;       // threads per workgroup (4 waves)
+constexpr int kStreamNnz = 2048;  // products staged in LDS per workgroup (16 KiB)
+constexpr int kMaxPartials = 1 << 20;
+
+// epilogue selector of the CSR-stream kernel: what happens to the row sum s_i = (A x)_i
+enum CsrOp : int {
+    OP_SPMV = 0,      // y_i = s_i
+    OP_RESID = 1,     // y_i = b_i - s_i                          (store_residual)
+    OP_JACOBI = 2,    // y_i = x_i + omega*(b_i - s_i)/d_i        (one fused Jacobi sweep, y != x)
+    OP_ADD = 3,       // y_i = s_i + y_i                          (transfer_solution, beta = 1)
+    OP_SPMV_DOT = 4,  // y_i = s_i ; partial += x_i*s_i           (Ap and p.Ap of CG)
+    OP_RESNORM = 5,   // partial += (s_i - b_i)^2                 (residual norm, nothing stored)
+    OP_JACOBI_DOT = 6 // Jacobi sweep ; partial += y_i*b_i        (last post-sweep of PCG: z.r)
+};
+
+struct CsrArgs {
+    const double *x = nullptr;   // input vector (gathered)
+    const double *b = nullptr;   // rhs (RESID/JACOBI/RESNORM)
+    const double *d = nullptr;   // diagonal (JACOBI)
+    double *y = nullptr;         // output
+    double omega = 0.0;
+    double *partial = nullptr;   // per-block partial sums (reductions), size >= nblk
+};
+
+// host-side builder of the row-block schedule (returns number of blocks; out sized nrow+1 max)
+int build_rowblocks(int nrow, const int *rowptr, int *out);
+
+void launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool fine, hipStream_t st);
+
+// x_i = omega*b_i/d_i : first Jacobi sweep from a zero guess (bitwise equal to the full sweep)
+void launch_jacobi_zero(int n, const double *b, const double *d, double omega, double *x, hipStream_t st);
+// xf_i = xc[agg_i] + xf_i : prolongation for an aggregation P (one unit entry per row)
+void launch_prolong_agg(int n, const int *agg, const double *xc, double *xf, hipStream_t st);
+// x = A^{-1} b with the explicit row-major inverse (coarsest level)
+void launch_gemv(int n, const double *M, const double *b, double *x, hipStream_t st);
+
+// ---- BLAS-1 (daxpby/daxpbyc kernels, cublasDaxpy/Ddot/Dnrm2, thrust::fill of the reference)
+void launch_fill(int n, double v, double *x, hipStream_t st);
+void launch_copy(int n, const double *x, double *y, hipStream_t st);
+// y = a*x + b*y with host scalars
+void launch_axpby(int n, double a, const double *x, double b, double *y, hipStream_t st);
+// partial sums of x.y (nblocks returned through *nblk)
+void launch_dot(int n, const double *x, const double *y, double *partial, int *nblk, hipStream_t st);
+
+// device-resident scalar slots used by the Krylov loops
+enum Slot : int {
+    S_RZ = 0, S_PAP, S_ALPHA, S_NALPHA, S_BETA, S_RR, S_RES, S_ZR,
+    S_ALPHA1, S_APR0, S_ASS, S_ASAS, S_OMEGA1, S_RR0, S_TMP, S_COUNT
+};
+
+// finalize codes: reduce partial arrays, then one thread updates the scalar slots
+enum Fin : int {
+    FIN_STORE = 0,     // scal[slot_a] = sum0
+    FIN_SQRT = 1,      // scal[slot_a] = sqrt(sum0) ; hist[it] = that
+    FIN_PCG_ALPHA = 2, // pAp=sum0 ; alpha = rz/pAp ; nalpha = -alpha
+    FIN_PCG_BETA = 3,  // zr=sum0 ; beta = zr/rz ; rz = zr
+    FIN_CG_BETA = 4,   // rr_new=sum0 ; beta = rr_new/rr ; res = sqrt(rr*beta) ; rr = rr_new ; hist
+    FIN_CG_ALPHA = 5,  // pAp=sum0 ; alpha = rr/pAp ; nalpha = -alpha
+    FIN_BICG_ALPHA = 6,// alpha1 = sum0 (r.r0) ; apr0 = sum1 (Ap.r0) ; alpha = alpha1/apr0
+    FIN_BICG_OMEGA = 7,// ass = sum0 (As.s) ; asas = sum1 (As.As) ; omega1 = ass/asas
+    FIN_BICG_BETA = 8  // rr0 = sum0 (r.r0) ; rr = sum1 (r.r) ; beta = rr0/alpha1*(alpha/omega1) ; res = sqrt(rr) ; hist
+};
+void launch_finalize(Fin code, const double *partial0, const double *partial1, int nblk, double *scal, int slot_a,
+                     double *hist, int it, hipStream_t st);
+
+// Krylov vector updates with device-resident coefficients (no host round trip)
+// PCG/CG: x += alpha p ; r += (-alpha) Ap ; partial += r_i^2
+void launch_cg_update(int n, const double *scal, const double *p, const double *Ap, double *x, double *r, double *partial,
+                      int *nblk, hipStream_t st);
+// p = 1.0*z + beta*p
+void launch_p_update(int n, const double *scal, const double *z, double *p, hipStream_t st);
+// two dots at once: partial0 += a.b, partial1 += c.d
+void launch_dot2(int n, const double *a, const double *b, const double *c, const double *d, double *partial0, double *partial1,
+                 int *nblk, hipStream_t st);
+// BiCGStab: s = r - alpha*Ap
+void launch_bicg_s(int n, const double *scal, const double *r, const double *Ap, double *s, hipStream_t st);
+// BiCGStab: x = x + alpha*p1 + omega1*s1 ; r = s - omega1*As ; partial0 += r.r0 ; partial1 += r.r
+void launch_bicg_xr(int n, const double *scal, const double *p1, const double *s1, const double *s, const double *As,
+                    const double *r0, double *x, double *r, double *partial0, double *partial1, int *nblk, hipStream_t st);
+// BiCGStab: p = r + beta*(p - omega1*Ap)
+void launch_bicg_p(int n, const double *scal, const double *r, const double *Ap, double *p, hipStream_t st);
+
+}  // namespace sparsh

@@ -1,0 +1,238 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  GPU box only.
+
+Tolerances: SpMV-type kernels add products in stored order with separately
+rounded multiply and add (-ffp-contract=off on both sides) -> compared BITWISE; reductions
+rtol 1e-12; residual histories 1e-6 relative while r_k >= 1e-6 r_0 and 1e-3 below; final
+solution 1e-8 relative in the 2-norm.
+"""
+import numpy as np
+import pytest
+
+import oracle
+import sparsh_amg_amd as sa
+from sparsh_amg_amd import problems
+from conftest import hist_tolerance
+
+pytestmark = pytest.mark.gpu
+
+QUIET = dict(print_setup=0, print_solve=0)
+
+
+def _mk(rp, ci, v, **kw):
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET, **kw))
+    O = oracle.Csr(rp, ci, v)
+    return A, O
+
+
+CASES = {
+    "p2d": lambda: problems.poisson2d(150),
+    "p3d": lambda: problems.poisson3d(30),
+    "ragged": lambda: problems.random_spd(20000, 9, seed=11),
+}
+
+
+@pytest.fixture(scope="module", params=list(CASES))
+def case(request):
+    rp, ci, v = CASES[request.param]()
+    A, O = _mk(rp, ci, v)
+    H = oracle.Hierarchy(O)
+    return request.param, A, O, H
+
+
+def test_kernels_bitwise(case):
+    name, A, O, H = case
+    rng = np.random.default_rng(7)
+    assert A.nlevels == H.nlevels
+    for l in range(A.nlevels):
+        n = A.level_info(l)["nrow"]
+        x = rng.standard_normal(n)
+        b = rng.standard_normal(n)
+        Ol = H.A(l)
+        assert np.array_equal(A.op_spmv(l, x), oracle.spmv(Ol, x)), f"spmv level {l}"
+        assert np.array_equal(A.op_residual(l, b, x), oracle.store_residual(Ol, b, x)), f"residual level {l}"
+        for sweeps in (1, 2, 7):
+            assert np.array_equal(A.op_jacobi(l, b, x, sweeps), oracle.jacobi(Ol, b, x, sweeps - 1)), f"jacobi x{sweeps} level {l}"
+        # zero-guess shortcut == full sweeps from x = 0
+        assert np.array_equal(A.op_jacobi(l, b, np.zeros(n), 7, x_is_zero=True), oracle.jacobi(Ol, b, np.zeros(n), 6))
+        rn = A.op_resnorm(l, b, x)
+        assert abs(rn - oracle.residual(Ol, b, x)) <= 1e-12 * rn
+        if l + 1 < A.nlevels:
+            nc = A.level_info(l + 1)["nrow"]
+            xc = rng.standard_normal(nc)
+            assert np.array_equal(A.op_restrict(l, x), oracle.transfer_residual(H.P(l), x)), f"restrict level {l}"
+            assert np.array_equal(A.op_prolong(l, xc, x), oracle.transfer_solution(H.P(l), xc, x)), f"prolong level {l}"
+    nL = A.level_info(A.nlevels - 1)["nrow"]
+    bc = rng.standard_normal(nL)
+    xg = A.op_coarse(bc)
+    xo = H.coarse_solve(bc)
+    assert np.linalg.norm(xg - xo) <= 1e-10 * np.linalg.norm(xo)
+
+
+def test_blas1(case):
+    _, A, _, _ = case
+    rng = np.random.default_rng(8)
+    for n in (1, 63, 64, 65, 1000, 123457):
+        x = rng.standard_normal(n)
+        y = rng.standard_normal(n)
+        d = A.op_dot(x, y)
+        ref = float(np.dot(x.astype(np.longdouble), y.astype(np.longdouble)))
+        scale = float(np.dot(np.abs(x), np.abs(y)))
+        assert abs(d - ref) <= 1e-13 * scale
+        assert abs(A.op_nrm2(x) - np.linalg.norm(x)) <= 1e-13 * np.linalg.norm(x)
+        assert np.array_equal(A.op_axpby(0.3, x, -1.7, y), 0.3 * x + (-1.7) * y)
+
+
+def test_reductions_reproducible(case):
+    _, A, _, _ = case
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(200001)
+    y = rng.standard_normal(200001)
+    vals = {A.op_dot(x, y) for _ in range(5)}
+    assert len(vals) == 1  # two-stage fixed-order reduction, no atomics
+
+
+def _hist_ok(h, ho):
+    assert len(h) == len(ho), (len(h), len(ho))
+    tol = hist_tolerance(ho)
+    err = np.abs(h - ho) / ho
+    assert np.all(err <= tol), f"max rel err {err.max():.3e} at {err.argmax()}"
+
+
+@pytest.mark.parametrize("method", ["amg", "pcg", "pbicg", "cg"])
+def test_solver_history(case, method):
+    name, A, O, _ = case
+    n = A.nrow
+    b = np.ones(n)
+    x = np.zeros(n)
+    h, rc = A.solve(method, b, x)
+    xo, ho = oracle.solve(method, O, b)
+    assert rc == 0
+    if method == "cg":
+        # hundreds of un-preconditioned iterations: rounding decorrelates the tail; pin the head
+        k = min(20, len(h), len(ho))
+        assert np.allclose(h[:k], ho[:k], rtol=1e-9)
+        assert abs(len(h) - len(ho)) <= max(3, len(ho) // 50)
+    else:
+        _hist_ok(h, ho)
+    assert np.linalg.norm(x - xo) <= 1e-8 * np.linalg.norm(xo)
+    S = O.to_scipy()
+    assert np.linalg.norm(b - S @ x) <= 1.0001e-8
+
+
+def test_bicg_head(case):
+    name, A, O, _ = case
+    n = A.nrow
+    b = np.ones(n)
+    x = np.zeros(n)
+    h, rc = A.solve("bicg", b, x)
+    _, ho = oracle.solve("bicg", O, b)
+    k = min(10, len(h), len(ho))
+    assert np.allclose(h[:k], ho[:k], rtol=1e-8)
+    assert np.linalg.norm(b - O.to_scipy() @ x) <= 1.0001e-8
+
+
+def test_nonzero_initial_guess(case):
+    _, A, O, _ = case
+    n = A.nrow
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal(n)
+    x0 = rng.standard_normal(n)
+    for method in ("amg", "pcg"):
+        x = x0.copy()
+        h, rc = A.solve(method, b, x)
+        xo, ho = oracle.solve(method, O, b, x0=x0)
+        _hist_ok(h, ho)
+        assert np.linalg.norm(x - xo) <= 1e-8 * np.linalg.norm(xo)
+
+
+def test_fixed_cycle_count(case):
+    _, A, O, H = case
+    n = A.nrow
+    b = np.ones(n)
+    x = np.zeros(n)
+    h, _ = A.vcycle(b, x, iterations=3)
+    xo, ho = H.solve(b, iterations=3)
+    assert len(h) == 3 and np.allclose(h, ho, rtol=1e-10)
+    assert np.linalg.norm(x - xo) <= 1e-11 * np.linalg.norm(xo)
+
+
+def test_golden_histories(golden):
+    """Device path vs the reference's own outputs."""
+    rp, ci, v = problems.poisson3d(40)
+    A, _ = _mk(rp, ci, v)
+    g = golden["poisson3d_40"]["hem"]
+    b = np.ones(A.nrow)
+    x = np.zeros(A.nrow)
+    h, _ = A.solve("pcg", b, x)
+    _hist_ok(h, np.array(g["pcg"]["hist"]))
+    x[:] = 0
+    h, _ = A.solve("pbicg", b, x)
+    _hist_ok(h, np.array(g["pbicg"]["hist"]))
+    x[:] = 0
+    h, _ = A.solve("amg", b, x)
+    assert len(h) == g["amg"]["cycles"]
+    assert np.allclose(h[:5], g["amg"]["hist_head"], rtol=1e-9)
+    assert abs(np.linalg.norm(x) - g["amg"]["xnorm"]) <= 1e-9 * g["amg"]["xnorm"]
+    rp, ci, v = problems.poisson2d(256)
+    A, _ = _mk(rp, ci, v)
+    g = golden["poisson2d_256"]["hem"]
+    x = np.zeros(A.nrow)
+    h, _ = A.solve("pcg", np.ones(A.nrow), x)
+    assert len(h) == g["pcg"]["iterations"]
+    assert np.allclose(h[:5], g["pcg"]["hist_head"], rtol=1e-9)
+    assert abs(np.linalg.norm(x) - g["pcg"]["xnorm"]) <= 1e-9 * g["pcg"]["xnorm"]
+
+
+def test_beck_coarsening():
+    rp, ci, v = problems.poisson3d(30)
+    A, O = _mk(rp, ci, v, coarsening=1)
+    b = np.ones(A.nrow)
+    x = np.zeros(A.nrow)
+    h, rc = A.solve("amg", b, x)
+    H = oracle.Hierarchy(O, oracle.params(coarsening=1))
+    xo, ho = H.solve(b)
+    _hist_ok(h, ho)
+    assert np.linalg.norm(x - xo) <= 1e-8 * np.linalg.norm(xo)
+
+
+def test_edge_cases():
+    # single level (n <= limit_upper): the V-cycle is the direct solve
+    rp, ci, v = problems.poisson2d(30)
+    A, O = _mk(rp, ci, v)
+    assert A.nlevels == 1
+    b = np.ones(A.nrow)
+    x = np.zeros(A.nrow)
+    h, rc = A.solve("pcg", b, x)
+    assert rc == 0 and len(h) <= 2
+    assert np.linalg.norm(b - O.to_scipy() @ x) <= 1e-8
+    # a matrix with empty rows and one very long row (own-workgroup path of the CSR kernel)
+    import scipy.sparse as sp
+
+    n = 6000
+    rng = np.random.default_rng(5)
+    M = sp.random(n, n, density=0.001, random_state=6, format="lil")
+    M[17, :] = rng.standard_normal(n)  # 6000 entries > LDS product buffer
+    M[100, :] = 0
+    M[101, :] = 0
+    M = (M.tocsr() + sp.diags(np.full(n, 50.0))).tolil()
+    M[100, :] = 0  # truly empty rows
+    M[101, :] = 0
+    M = M.tocsr()
+    M.sort_indices()
+    A2 = sa.sp_matrix_mg(M.indptr, M.indices, M.data).setup(sa.default_params(**QUIET, limit_upper=10000))
+    x = rng.standard_normal(n)
+    y = A2.op_spmv(0, x)
+    yo = oracle.spmv(oracle.Csr(M.indptr, M.indices, M.data), x)
+    assert y[100] == 0.0 and y[101] == 0.0
+    mask = np.ones(n, bool)
+    mask[17] = False
+    assert np.array_equal(y[mask], yo[mask])
+    assert abs(y[17] - yo[17]) <= 1e-12 * np.abs(M[17].toarray()).ravel() @ np.abs(x)
+
+
+def test_max_iter_cap_reports_noconv():
+    rp, ci, v = problems.poisson3d(30)
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET, max_iter=3))
+    x = np.zeros(A.nrow)
+    h, rc = A.solve("pcg", np.ones(A.nrow), x)
+    assert rc == sa.SPARSH_ENOCONV and len(h) == 3

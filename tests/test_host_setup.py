@@ -1,0 +1,146 @@
+"""Host half of the product (coarsening, Galerkin, coarse inverse) vs the oracle; and the C-ABI
+load/export check.  CPU only -- no compute kernel is called."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+import sparsh_amg_amd as sa
+from sparsh_amg_amd import problems
+from conftest import C0_MATRIX, C0_RHS, ROOT
+
+
+def _same_hierarchy(A: sa.sp_matrix_mg, H: oracle.Hierarchy):
+    assert A.nlevels == H.nlevels
+    for l in range(A.nlevels):
+        rp, ci, v, _ = A.level_csr(l, "A")
+        orp, oci, ov = H.A(l).arrays()
+        assert np.array_equal(rp, orp) and np.array_equal(ci, oci)
+        # the aggregation-specialised Galerkin product adds in the same order as the oracle's
+        # two-product form: bitwise equal
+        assert np.array_equal(v, ov), f"level {l}: max diff {np.abs(v - ov).max()}"
+        if l + 1 < A.nlevels:
+            rp, ci, v, ncol = A.level_csr(l, "P")
+            orp, oci, ov = H.P(l).arrays()
+            assert ncol == H.P(l).shape[1]
+            assert np.array_equal(rp, orp) and np.array_equal(ci, oci) and np.array_equal(v, ov)
+
+
+@pytest.mark.parametrize("gen,kw", [("poisson2d", dict(n=96)), ("poisson3d", dict(n=24)), ("random_spd", dict(n=9000, nnz_per_row=8, seed=5))])
+def test_hierarchy_matches_oracle_hem(gen, kw):
+    rp, ci, v = getattr(problems, gen)(**kw)
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0), host_only=True)
+    H = oracle.Hierarchy(oracle.Csr(rp, ci, v))
+    _same_hierarchy(A, H)
+
+
+@pytest.mark.parametrize("gen,kw", [("poisson3d", dict(n=24)), ("random_spd", dict(n=9000, nnz_per_row=8, seed=6))])
+def test_hierarchy_matches_oracle_beck(gen, kw):
+    rp, ci, v = getattr(problems, gen)(**kw)
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, coarsening=1), host_only=True)
+    H = oracle.Hierarchy(oracle.Csr(rp, ci, v), oracle.params(coarsening=1))
+    assert A.nlevels == H.nlevels
+    for l in range(A.nlevels):
+        S = A.level_scipy(l, "A")
+        O = H.A(l).to_scipy()
+        assert S.shape == O.shape and S.nnz == O.nnz
+        assert abs(S - O).max() <= 1e-13 * abs(O).max()
+
+
+def test_c0_hierarchy_golden(have_c0, golden):
+    if not have_c0:
+        pytest.skip("bundled matrix lives in /root/reference (build container only)")
+    A, b = sa.readcoo(C0_MATRIX, C0_RHS)
+    A.setup(sa.default_params(print_setup=0), host_only=True)
+    g = golden["C0"]["hem"]
+    assert [A.level_info(l)["nrow"] for l in range(A.nlevels)] == g["levels_nrow"]
+    assert [A.level_info(l)["nnz"] for l in range(A.nlevels)] == g["levels_nnz_stored"]
+    assert abs(np.linalg.norm(b) - 10.8032) < 1e-3
+
+
+def test_golden_level_shapes(golden):
+    for key, gen in (("poisson2d_256", lambda: problems.poisson2d(256)), ("poisson3d_40", lambda: problems.poisson3d(40))):
+        rp, ci, v = gen()
+        A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0), host_only=True)
+        g = golden[key]["hem"]
+        assert [A.level_info(l)["nrow"] for l in range(A.nlevels)] == g["levels_nrow"]
+        assert [A.level_info(l)["nnz"] for l in range(A.nlevels)] == g["levels_nnz_stored"]
+
+
+def test_coarse_inverse():
+    rp, ci, v = problems.poisson3d(20)
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0), host_only=True)
+    AL = A.level_scipy(A.nlevels - 1, "A")
+    inv = A.coarse_inverse()
+    n = AL.shape[0]
+    assert 2000 <= n <= 4000
+    err = np.abs(AL @ inv - np.eye(n)).max()
+    assert err < 1e-12
+    # against the oracle's direct solve
+    H = oracle.Hierarchy(oracle.Csr(rp, ci, v))
+    b = np.random.default_rng(0).standard_normal(n)
+    assert np.allclose(inv @ b, H.coarse_solve(b), rtol=1e-11, atol=1e-13)
+
+
+def test_coarse_inverse_needs_pivoting():
+    # non-symmetric, not diagonally dominant: exercises the row interchanges of the banded LU
+    rng = np.random.default_rng(3)
+    n = 600
+    import scipy.sparse as sp
+
+    M = sp.random(n, n, density=0.01, random_state=4, format="csr") + sp.diags(rng.standard_normal(n) * 0.05)
+    M = (M + sp.diags(np.ones(n - 1), 1) + sp.diags(np.ones(n - 1) * 0.5, -1)).tocsr()
+    M.sort_indices()
+    A = sa.sp_matrix_mg(M.indptr, M.indices, M.data).setup(sa.default_params(print_setup=0), host_only=True)
+    assert A.nlevels == 1
+    inv = A.coarse_inverse()
+    assert np.abs(M @ inv - np.eye(n)).max() < 1e-8
+
+
+def test_extended_hierarchy():
+    # max_levels too small for coarse_limit: hierarchy is extended (documented deviation)
+    rp, ci, v = problems.poisson2d(200)
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, max_levels=2, coarse_limit=5000), host_only=True)
+    assert A.nlevels > 2
+    assert A.level_info(A.nlevels - 1)["nrow"] <= 5000
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "sparsh_amg.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(sparsh_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 30
+    import ctypes
+
+    L = ctypes.CDLL(sa.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_no_gpu_fails_loudly():
+    if sa.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    rp, ci, v = problems.poisson2d(40)
+    A = sa.sp_matrix_mg(rp, ci, v)
+    with pytest.raises(sa.SparshError) as e:
+        A.setup(sa.default_params(print_setup=0))
+    assert e.value.code == sa.SPARSH_ENODEV
+    # solvers refuse to run without a device-side setup: no CPU fallback
+    A.setup(sa.default_params(print_setup=0), host_only=True)
+    with pytest.raises(sa.SparshError) as e:
+        A.solve("pcg", np.ones(A.nrow), np.zeros(A.nrow))
+    assert e.value.code == sa.SPARSH_ESTATE
+
+
+def test_product_does_not_touch_oracle():
+    # the product tree must not reference oracle/ in any form
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "sparsh_amg_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"amg_oracle|import oracle|from oracle|oracle/", txt):
+                    bad.append(f)
+    assert not bad, bad
