@@ -69,6 +69,7 @@ typedef struct sparsh_handle_s *sparsh_handle;
 const char *sparsh_last_error(void);
 int sparsh_version(void);
 int sparsh_device_count(void);
+int sparsh_host_cpus(void); /* CPUs this process may use (affinity mask and cgroup quota) */
 
 void sparsh_default_params(sparsh_params *p);
 
@@ -83,6 +84,10 @@ void sparsh_destroy(sparsh_handle h);
  * AMG_GPU1_solver::GPU_Allocations does (src/AMG_gpu_phases_2.cu:13-94): build the hierarchy
  * on the host, factor the coarsest level, upload everything to HBM (resident). */
 int sparsh_setup(sparsh_handle h, const sparsh_params *p);
+
+/* Change the stopping rule of an already set-up handle (tol1 of include/AMG.hpp:18; iteration
+ * cap; how often the residual norm is read back).  max_iter/check_every <= 0 keep their value. */
+int sparsh_set_stopping(sparsh_handle h, double tol, int max_iter, int check_every);
 
 /* Host half of sparsh_setup only (coarsening, Galerkin products, coarse factorisation); needs
  * no GPU.  Enables the inspection calls below; solvers still require sparsh_setup. */

@@ -71,11 +71,13 @@ def _load():
         "sparsh_last_error": (C.c_char_p, []),
         "sparsh_version": (C.c_int, []),
         "sparsh_device_count": (C.c_int, []),
+        "sparsh_host_cpus": (C.c_int, []),
         "sparsh_default_params": (None, [P(Params)]),
         "sparsh_create_csr": (C.c_int, [C.c_int, C.c_int, c_int_p, c_int_p, c_dbl_p, P(H)]),
         "sparsh_destroy": (None, [H]),
         "sparsh_setup": (C.c_int, [H, P(Params)]),
         "sparsh_setup_host": (C.c_int, [H, P(Params)]),
+        "sparsh_set_stopping": (C.c_int, [H, C.c_double, C.c_int, C.c_int]),
         "sparsh_num_levels": (C.c_int, [H]),
         "sparsh_level_info": (C.c_int, [H, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p]),
         "sparsh_level_csr": (C.c_int, [H, C.c_int, C.c_int, c_int_p, c_int_p, c_dbl_p]),
@@ -144,6 +146,11 @@ def device_count() -> int:
     return lib.sparsh_device_count()
 
 
+def host_cpus() -> int:
+    """CPUs this process may use (affinity mask capped by the cgroup quota)."""
+    return lib.sparsh_host_cpus()
+
+
 class sp_matrix_mg:
     """Host CSR container named after the reference's class (include/AMG_cpu_matrix.hpp:12-51).
 
@@ -184,6 +191,9 @@ class sp_matrix_mg:
         fn = lib.sparsh_setup_host if host_only else lib.sparsh_setup
         _check(fn(self._h, C.byref(self.params)))
         return self
+
+    def set_stopping(self, tol, max_iter=0, check_every=0):
+        _check(lib.sparsh_set_stopping(self._h, tol, max_iter, check_every))
 
     @property
     def nlevels(self):

@@ -78,6 +78,8 @@ const char *sparsh_last_error(void) { return g_err.c_str(); }
 
 int sparsh_version(void) { return 100; }
 
+int sparsh_host_cpus(void) { return effective_cpus(); }
+
 int sparsh_device_count(void)
 {
     int n = 0;
@@ -148,6 +150,13 @@ int sparsh_setup_host(sparsh_handle h, const sparsh_params *p)
     int rc = h->eng->setup_host(prm);
     if (rc != SPARSH_OK) return fail(rc, h->eng->error);
     return rc;
+}
+
+int sparsh_set_stopping(sparsh_handle h, double tol, int max_iter, int check_every)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    h->eng->set_stopping(tol, max_iter, check_every);
+    return SPARSH_OK;
 }
 
 int sparsh_num_levels(sparsh_handle h)

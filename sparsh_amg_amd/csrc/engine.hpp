@@ -54,6 +54,12 @@ public:
     hipStream_t stream() const { return st_; }
     const DevLevel &level(int l) const { return lev_[l]; }
     int n0() const { return A0_.nrow; }
+    void set_stopping(double tol, int max_iter, int check_every)
+    {
+        prm_.tol = tol;
+        if (max_iter > 0) prm_.max_iter = max_iter;
+        if (check_every > 0) prm_.check_every = check_every;
+    }
 
     // solvers on device vectors; return SPARSH_* code; iterations through *iters
     int solve_dev(int method, const double *b_dev, double *x_dev, int max_iters, double *hist, int hist_cap, int *iters,

@@ -18,6 +18,8 @@
 #include <cstring>
 #include <numeric>
 #include <omp.h>
+#include <sched.h>
+#include <unistd.h>
 
 namespace sparsh {
 
@@ -36,6 +38,41 @@ void prefix(std::vector<int> &rp)
 }
 
 }  // namespace
+
+// CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota.  A
+// container on a 256-thread host may own 16 of them; an OpenMP team of 256 spinning threads
+// on 16 CPUs is orders of magnitude slower than a team of 16.
+int effective_cpus()
+{
+    int n = 0;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = (int)sysconf(_SC_NPROCESSORS_ONLN);
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[64];
+        long period = 0;
+        if (std::fscanf(f, "%63s %ld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0) {
+            const long q = std::atol(quota);
+            const int c = (int)((q + period - 1) / period);
+            if (c > 0 && c < n) n = c;
+        }
+        std::fclose(f);
+    } else if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        long q = -1, period = 100000;
+        if (std::fscanf(g, "%ld", &q) != 1) q = -1;
+        std::fclose(g);
+        if (FILE *h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (std::fscanf(h, "%ld", &period) != 1) period = 100000;
+            std::fclose(h);
+        }
+        if (q > 0 && period > 0) {
+            const int c = (int)((q + period - 1) / period);
+            if (c > 0 && c < n) n = c;
+        }
+    }
+    return std::max(1, std::min(n, 64));
+}
 
 std::vector<double> extract_diagonal(const HostCsr &A)
 {
@@ -506,7 +543,7 @@ bool sparse_inverse(const HostCsr &A, std::vector<double> &inv)
 bool build_hierarchy(const HostCsr &A0, const SetupParams &prm, HostHierarchy &H)
 {
     const double t0 = wall();
-    if (prm.host_threads > 0) omp_set_num_threads(prm.host_threads);
+    omp_set_num_threads(prm.host_threads > 0 ? prm.host_threads : effective_cpus());
     H.levels.clear();
     H.levels.emplace_back();
     H.levels[0].A = HostCsr::alias(A0.nrow, A0.ncol, A0.rowptr, A0.col, A0.val);
@@ -517,8 +554,11 @@ bool build_hierarchy(const HostCsr &A0, const SetupParams &prm, HostHierarchy &H
     for (;;) {
         const int n = H.levels[l].A.nrow;
         const bool within_ref = l < prm.max_levels - 1;
-        if (!(n > prm.limit_upper && (within_ref || n > prm.coarse_limit))) break;
-        if (!within_ref) H.extended = true;
+        // reference rule: coarsen while n > limit_upper and fewer than max_levels levels exist.
+        // Deviation: if that leaves a coarsest level above coarse_limit (the device applies a dense
+        // inverse), keep coarsening by the same rule until n <= limit_upper.
+        if (!within_ref && n > prm.coarse_limit) H.extended = true;
+        if (!(n > prm.limit_upper && (within_ref || H.extended))) break;
         if (prm.print) std::printf("Level %d:\t%d\n", l, n);
         HostLevel &L = H.levels[l];
         if (prm.coarsening == 1) {

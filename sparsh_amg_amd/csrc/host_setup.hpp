@@ -68,6 +68,8 @@ struct HostHierarchy {
     std::string error;
 };
 
+int effective_cpus();  // CPUs usable by this process (affinity and cgroup quota)
+
 // individual steps (exposed for tests through the C ABI)
 HostCsr hem_prolongator(const HostCsr &A, int level);
 HostCsr beck_prolongator(const HostCsr &A);
