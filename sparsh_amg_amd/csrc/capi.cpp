@@ -465,7 +465,13 @@ int sparsh_sync(sparsh_handle h)
 int sparsh_profile(sparsh_handle h, int enable)
 {
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
-    h->eng->prof.enabled = enable != 0;
+    if (enable) {
+        h->eng->profile_begin();
+        h->eng->prof.enabled = true;
+    } else if (h->eng->prof.enabled) {
+        h->eng->profile_collect();
+        h->eng->prof.enabled = false;
+    }
     return SPARSH_OK;
 }
 

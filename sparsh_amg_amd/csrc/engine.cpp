@@ -527,6 +527,31 @@ int Engine::bicg(const double *b, double *x, int max_iters, double *hist, int hi
     return rc;
 }
 
+void Engine::profile_begin()
+{
+    if (prof.ev.empty()) {
+        prof.ev.resize(kProfEvents);
+        for (auto &e : prof.ev) (void)hipEventCreate(&e);
+    }
+    prof.used = 0;
+    prof.launches = 0;
+    prof.seconds = 0;
+}
+
+void Engine::profile_collect()
+{
+    if (st_) (void)hipStreamSynchronize(st_);
+    prof.launches = 0;
+    prof.seconds = 0;
+    for (size_t k = 0; k + 1 < prof.used; k += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, prof.ev[k], prof.ev[k + 1]) == hipSuccess) {
+            prof.seconds += ms * 1e-3;
+            prof.launches += 1;
+        }
+    }
+}
+
 int Engine::solve_dev(int method, const double *b, double *x, int max_iters, double *hist, int hist_cap, int *iters, double *seconds)
 {
     if (!ready_) {
@@ -534,13 +559,7 @@ int Engine::solve_dev(int method, const double *b, double *x, int max_iters, dou
         return SPARSH_ESTATE;
     }
     if (max_iters <= 0) max_iters = prm_.max_iter;
-    if (prof.enabled) {
-        if (prof.ev.empty()) {
-            prof.ev.resize(kProfEvents);
-            for (auto &e : prof.ev) (void)hipEventCreate(&e);
-        }
-        prof.used = 0;
-    }
+    if (prof.enabled) profile_begin();
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (seconds) {
         (void)hipEventCreate(&e0);
@@ -568,18 +587,7 @@ int Engine::solve_dev(int method, const double *b, double *x, int max_iters, dou
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
     }
-    if (prof.enabled) {
-        (void)hipStreamSynchronize(st_);
-        prof.launches = 0;
-        prof.seconds = 0;
-        for (size_t k = 0; k + 1 < prof.used; k += 2) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, prof.ev[k], prof.ev[k + 1]) == hipSuccess) {
-                prof.seconds += ms * 1e-3;
-                prof.launches += 1;
-            }
-        }
-    }
+    if (prof.enabled) profile_collect();
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
         error = std::string("HIP error during solve: ") + hipGetErrorString(le);

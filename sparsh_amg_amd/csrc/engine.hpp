@@ -89,6 +89,8 @@ public:
     std::string error;
 
     ProfileData prof;
+    void profile_begin();    // (re)arm the event pool
+    void profile_collect();  // sync and sum the recorded launch times
     double setup_seconds = 0.0;
 
 private:

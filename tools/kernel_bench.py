@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Per-operator, per-level achieved bandwidth of the resident hierarchy (HIP events, C ABI
+sparsh_bench_op).  Usage: python tools/kernel_bench.py [--n 216] [--reps 20] [--levels 4]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sparsh_amg_amd as sa
+from sparsh_amg_amd import problems
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=216)
+    ap.add_argument("--dim", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--levels", type=int, default=4)
+    a = ap.parse_args()
+    rp, ci, v = problems.poisson3d(a.n) if a.dim == 3 else problems.poisson2d(a.n)
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, print_solve=0))
+    print(f"{'op':10s} {'lvl':>3s} {'rows':>10s} {'nnz':>10s} {'us':>9s} {'GB/s':>8s} {'frac8T':>7s}")
+    for l in range(min(a.levels, A.nlevels)):
+        i = A.level_info(l)
+        n, nnz, pn, pnnz = i["nrow"], i["nnz"], i["p_ncol"], i["p_nnz"]
+        model = {
+            "spmv": 12 * nnz + 20 * n,
+            "jacobi": 12 * nnz + 36 * n,
+            "residual": 12 * nnz + 28 * n,
+            "dot": 16 * n,
+            "axpby": 24 * n,
+        }
+        if l + 1 < A.nlevels:
+            model["restrict"] = 12 * pnnz + 8 * n + 12 * pn
+            model["prolong"] = 12 * pnnz + 20 * n + 8 * pn
+        for op, nbytes in model.items():
+            sec = A.bench_op(op, l, a.reps)
+            gbs = nbytes / sec / 1e9
+            print(f"{op:10s} {l:3d} {n:10d} {nnz:10d} {sec * 1e6:9.1f} {gbs:8.1f} {gbs / 8000:7.3f}", flush=True)
+    nL = A.level_info(A.nlevels - 1)["nrow"]
+    sec = A.bench_op("coarse", A.nlevels - 1, a.reps)
+    print(f"{'coarse':10s} {A.nlevels - 1:3d} {nL:10d} {nL * nL:10d} {sec * 1e6:9.1f} {8 * nL * nL / sec / 1e9:8.1f}")
+
+
+if __name__ == "__main__":
+    main()
