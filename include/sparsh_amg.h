@@ -89,6 +89,14 @@ int sparsh_setup(sparsh_handle h, const sparsh_params *p);
  * cap; how often the residual norm is read back).  max_iter/check_every <= 0 keep their value. */
 int sparsh_set_stopping(sparsh_handle h, double tol, int max_iter, int check_every);
 
+/* Process-wide choice of the SpMV-type kernel family (A/B measurements; all families produce
+ * bitwise identical results).  kind: 0 workgroup CSR-stream, 1 wave CSR-stream, 2 sliced-ELL mirror
+ * where the operator is regular enough (falls back to 0 otherwise); vec: paired 16-B/8-B loads in
+ * the stream phase; nt: non-temporal loads for the matrix stream; remap: 0 none, 1 each XCD owns a
+ * contiguous eighth of the row blocks, G > 1 groups of G row blocks dealt round-robin to the XCDs.
+ * nt < 0 or remap < 0 selects the built-in per-operator policy (default). */
+int sparsh_set_kernel_config(int kind, int vec, int nt, int remap);
+
 /* Host half of sparsh_setup only (coarsening, Galerkin products, coarse factorisation); needs
  * no GPU.  Enables the inspection calls below; solvers still require sparsh_setup. */
 int sparsh_setup_host(sparsh_handle h, const sparsh_params *p);

@@ -78,6 +78,7 @@ def _load():
         "sparsh_setup": (C.c_int, [H, P(Params)]),
         "sparsh_setup_host": (C.c_int, [H, P(Params)]),
         "sparsh_set_stopping": (C.c_int, [H, C.c_double, C.c_int, C.c_int]),
+        "sparsh_set_kernel_config": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
         "sparsh_num_levels": (C.c_int, [H]),
         "sparsh_level_info": (C.c_int, [H, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p]),
         "sparsh_level_csr": (C.c_int, [H, C.c_int, C.c_int, c_int_p, c_int_p, c_dbl_p]),
@@ -140,6 +141,11 @@ def default_params(**kw) -> Params:
             raise AttributeError(f"sparsh_params has no field {k}")
         setattr(p, k, v)
     return p
+
+
+def set_kernel_config(kind=2, vec=True, nt=-1, remap=-1):
+    """Select the SpMV-type kernel family (process-wide); see sparsh_set_kernel_config."""
+    _check(lib.sparsh_set_kernel_config(int(kind), int(vec), int(nt), int(remap)))
 
 
 def device_count() -> int:

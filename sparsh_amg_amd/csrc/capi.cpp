@@ -159,6 +159,18 @@ int sparsh_set_stopping(sparsh_handle h, double tol, int max_iter, int check_eve
     return SPARSH_OK;
 }
 
+int sparsh_set_kernel_config(int kind, int vec, int nt, int remap)
+{
+    if (kind < 0 || kind > 2) return fail(SPARSH_EINVAL, "kind must be 0 (workgroup CSR-stream), 1 (wave CSR-stream) or 2 (sliced ELL)");
+    KernelConfig &c = kernel_config();
+    c.kind = kind;
+    c.vec = vec != 0;
+    c.nt = nt > 0;
+    c.remap = remap < 0 ? 0 : remap;
+    c.auto_policy = (nt < 0 || remap < 0);
+    return SPARSH_OK;
+}
+
 int sparsh_num_levels(sparsh_handle h)
 {
     if (!h || !h->eng || !h->eng->host_ready()) return 0;

@@ -74,19 +74,73 @@ T *upload(Engine &E, const T *src, size_t count)
     return d;
 }
 
-bool upload_csr(Engine &E, const HostCsr &A, DevCsr &D)
+// col/val get kCsrPad zeroed tail entries: the paired loads of the stream kernels may read one
+// entry past the last row
+template <class T>
+T *upload_padded(Engine &E, const T *src, size_t count)
+{
+    T *d = static_cast<T *>(E.dalloc((count + kCsrPad) * sizeof(T)));
+    if (!d) return nullptr;
+    if (!E.check(hipMemset(d + count, 0, kCsrPad * sizeof(T)), "hipMemset")) return nullptr;
+    if (count && !E.check(hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy H2D")) return nullptr;
+    return d;
+}
+
+// sliced-ELL mirror (slices of 64 rows); built only when padding stays below 1/8 of the entries
+bool upload_sell(Engine &E, const HostCsr &A, DevCsr &D)
+{
+    const int n = A.nrow;
+    if (n < 64) return true;
+    const int nslice = (n + 63) / 64;
+    std::vector<int> sp((size_t)nslice + 1, 0);
+    long total = 0;
+    for (int s = 0; s < nslice; ++s) {
+        int mx = 0;
+        const int r1 = std::min(n, (s + 1) * 64);
+        for (int r = s * 64; r < r1; ++r) mx = std::max(mx, A.rowptr[r + 1] - A.rowptr[r]);
+        total += (long)mx * 64;
+        if (total >= (1l << 31) - 64) return true;  // would overflow int offsets: keep CSR only
+        sp[(size_t)s + 1] = (int)total;
+    }
+    const long nnz = A.nnz();
+    if (total > nnz + nnz / 8) return true;  // too ragged for ELL slices
+    std::vector<int> sc((size_t)total, 0);
+    std::vector<double> sv((size_t)total, 0.0);
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < n; ++r) {
+        const int s = r >> 6, lane = r & 63;
+        const long base = sp[s];
+        for (int j = A.rowptr[r], k = 0; j < A.rowptr[r + 1]; ++j, ++k) {
+            sc[(size_t)(base + (long)k * 64 + lane)] = A.col[j];
+            sv[(size_t)(base + (long)k * 64 + lane)] = A.val[j];
+        }
+    }
+    D.nslice = nslice;
+    D.sell_entries = total;
+    D.slice_ptr = upload(E, sp.data(), sp.size());
+    D.sell_col = upload(E, sc.data(), sc.size());
+    D.sell_val = upload(E, sv.data(), sv.size());
+    return D.slice_ptr && D.sell_col && D.sell_val;
+}
+
+bool upload_csr(Engine &E, const HostCsr &A, DevCsr &D, bool with_sell)
 {
     D.nrow = A.nrow;
     D.ncol = A.ncol;
     D.nnz = A.nnz();
     D.rowptr = upload(E, A.rowptr, (size_t)A.nrow + 1);
-    D.col = upload(E, A.col, (size_t)D.nnz);
-    D.val = upload(E, A.val, (size_t)D.nnz);
+    D.col = upload_padded(E, A.col, (size_t)D.nnz);
+    D.val = upload_padded(E, A.val, (size_t)D.nnz);
     std::vector<int> rb((size_t)A.nrow + 2);
     D.nblk = build_rowblocks(A.nrow, A.rowptr, rb.data());
     D.rowblk = upload(E, rb.data(), (size_t)D.nblk + 1);
-    return D.rowptr && D.col && D.val && D.rowblk;
+    D.nwblk = build_waveblocks(A.nrow, A.rowptr, rb.data());
+    D.waveblk = upload(E, rb.data(), (size_t)D.nwblk + 1);
+    if (with_sell && !upload_sell(E, A, D)) return false;
+    return D.rowptr && D.col && D.val && D.rowblk && D.waveblk;
 }
+
+int partial_count(const DevCsr &D) { return std::max(D.nblk, std::max((D.nwblk + 3) / 4, (D.nslice + 3) / 4)); }
 
 }  // namespace
 
@@ -140,7 +194,7 @@ int Engine::setup(const sparsh_params &p)
         const HostLevel &h = H_.levels[l];
         DevLevel &d = lev_[l];
         d.n = h.A.nrow;
-        if (!upload_csr(*this, h.A, d.A)) return SPARSH_ENODEV;
+        if (!upload_csr(*this, h.A, d.A, true)) return SPARSH_ENODEV;
         d.fine = (size_t)d.A.nnz * 12 + (size_t)d.n * 4 > kFineBytes;
         d.diag = upload(*this, h.diag.data(), (size_t)d.n);
         d.x = static_cast<double *>(dalloc((size_t)d.n * 8));
@@ -149,11 +203,11 @@ int Engine::setup(const sparsh_params &p)
         if (l > 0) d.b = static_cast<double *>(dalloc((size_t)d.n * 8));
         if (!d.diag || !d.x || !d.x2 || !d.r || (l > 0 && !d.b)) return SPARSH_ENODEV;
         if (l + 1 < nl) {
-            if (!upload_csr(*this, h.P, d.P) || !upload_csr(*this, h.R, d.R)) return SPARSH_ENODEV;
+            if (!upload_csr(*this, h.P, d.P, false) || !upload_csr(*this, h.R, d.R, false)) return SPARSH_ENODEV;
             d.P_is_aggregation = h.P_is_aggregation;
-            max_blk = std::max(max_blk, std::max(d.P.nblk, d.R.nblk));
+            max_blk = std::max(max_blk, std::max(partial_count(d.P), partial_count(d.R)));
         }
-        max_blk = std::max(max_blk, d.A.nblk);
+        max_blk = std::max(max_blk, partial_count(d.A));
         (void)hipMemsetAsync(d.x, 0, (size_t)d.n * 8, st_);
         (void)hipMemsetAsync(d.x2, 0, (size_t)d.n * 8, st_);
     }
@@ -222,8 +276,8 @@ double Engine::op_resnorm(int l, const double *b, const double *x)
     a.x = x;
     a.b = b;
     a.partial = part0_;
-    launch_csr(lev_[l].A, OP_RESNORM, a, lev_[l].fine, st_);
-    launch_finalize(FIN_SQRT, part0_, nullptr, lev_[l].A.nblk, scal_, S_RES, nullptr, 0, st_);
+    const int np = launch_csr(lev_[l].A, OP_RESNORM, a, lev_[l].fine, st_);
+    launch_finalize(FIN_SQRT, part0_, nullptr, np, scal_, S_RES, nullptr, 0, st_);
     return read_scalar(S_RES);
 }
 
@@ -281,12 +335,12 @@ void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, doubl
         if (last && dot_partial) {
             op = OP_JACOBI_DOT;
             a.partial = dot_partial;
-            *dot_nblk = L.A.nblk;
             dot_done = true;
         }
         const bool rec = timed && prof.used + 2 <= prof.ev.size();
         if (rec) (void)hipEventRecord(prof.ev[prof.used++], st_);
-        launch_csr(L.A, op, a, L.fine, st_);
+        const int np = launch_csr(L.A, op, a, L.fine, st_);
+        if (op == OP_JACOBI_DOT) *dot_nblk = np;
         if (rec) (void)hipEventRecord(prof.ev[prof.used++], st_);
         std::swap(L.x, L.x2);
     }
@@ -419,8 +473,8 @@ int Engine::pcg_steps(int nsteps, int *done)
         a.x = p;
         a.y = Ap;
         a.partial = part0_;
-        launch_csr(lev_[0].A, OP_SPMV_DOT, a, lev_[0].fine, st_);  // Ap = A p ; p.Ap
-        launch_finalize(precond ? FIN_PCG_ALPHA : FIN_CG_ALPHA, part0_, nullptr, lev_[0].A.nblk, scal_, 0, nullptr, 0, st_);
+        const int np = launch_csr(lev_[0].A, OP_SPMV_DOT, a, lev_[0].fine, st_);  // Ap = A p ; p.Ap
+        launch_finalize(precond ? FIN_PCG_ALPHA : FIN_CG_ALPHA, part0_, nullptr, np, scal_, 0, nullptr, 0, st_);
         launch_cg_update(n, scal_, p, Ap, x, r, part0_, &nb, st_);  // x += alpha p ; r -= alpha Ap ; r.r
         const int slot = std::min(count - 1, hist_cap_dev_ - 1);
         if (precond) {

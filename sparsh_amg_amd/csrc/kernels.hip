@@ -43,11 +43,29 @@ __device__ __forceinline__ double block_sum(double v, double *red)
 // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD, MI355X
 // microarch guide).  Give each XCD one contiguous range of row blocks so the x-vector lines
 // its neighbouring row blocks share stay in that XCD's 4 MiB L2.  Placement affects speed only.
-__device__ __forceinline__ int xcd_remap(int b, int nblk)
+// remap = 1: XCD x owns the x-th contiguous eighth of the row blocks.
+// remap = G > 1: XCD x owns the groups x, x+8, x+16, ... of G consecutive row blocks: all XCDs
+// sweep the same neighbourhood of the matrix at a time (DRAM locality), while blocks that share
+// x-vector lines (neighbours within a group) share an L2.
+__device__ __forceinline__ int xcd_remap(int b, int nblk, int mode)
 {
-    const int chunk = (nblk + 7) >> 3;
-    return (b & 7) * chunk + (b >> 3);
+    const int xcd = b & 7, i = b >> 3;
+    if (mode == 1) {
+        const int chunk = (nblk + 7) >> 3;
+        return xcd * chunk + i;
+    }
+    return ((i / mode) * 8 + xcd) * mode + (i % mode);
 }
+
+inline int remap_grid(int nblk, int mode)
+{
+    if (mode <= 0) return nblk;
+    const int q = 8 * (mode == 1 ? 1 : mode);
+    return ((nblk + q - 1) / q) * q;
+}
+
+using i2v = int __attribute__((ext_vector_type(2)));
+using d2v = double __attribute__((ext_vector_type(2)));
 
 template <bool NT>
 __device__ __forceinline__ double ld_stream(const double *p)
@@ -66,21 +84,163 @@ __device__ __forceinline__ int ld_stream(const int *p)
         return *p;
 }
 
-// ------------------------------------------------------------------ CSR-stream kernel
+// ------------------------------------------------------------------ SpMV-type kernels
 //
-// One workgroup owns a run of consecutive rows whose nnz fit the LDS product buffer.
-// Phase 1: the 256 threads walk the run's nnz range with unit stride -- val/col reads are
-// fully coalesced -- gather x[col] (L1/L2-served for banded matrices) and park the rounded
-// products in LDS.  Phase 2: one thread per row adds its products in stored order.
-// A row longer than the buffer is handled by a whole workgroup with a strided partial sum.
-template <int OP, bool NT>
-__global__ __launch_bounds__(kBlock) void csr_stream_kernel(const int *__restrict__ rowblk, int nblk,
-                                                             const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                             const double *__restrict__ val, CsrArgs a)
+// Three kernel families share one epilogue (what happens to the row sum) and one contract:
+// the products of a row are added one by one in stored order.
+//
+//  * csr_block_kernel (kind 0): a workgroup owns a run of consecutive rows whose products fit
+//    its LDS buffer.  Phase 1: 256 threads walk the run's nnz range with unit stride (coalesced
+//    val/col reads), gather x[col] and park the rounded products in LDS.  Phase 2: one thread
+//    per row adds its products.  Row operands (b, d, x_i, rowptr) are fetched before phase 1
+//    so their latency hides under the stream.
+//  * csr_wave_kernel (kind 1): the same per wave (64 rows, wave-private LDS slice), no
+//    workgroup barrier between the phases.
+//  * sell_kernel (kind 2): sliced-ELL mirror, lane = row, no LDS: every load of a wave is one
+//    contiguous segment (and for stencil matrices so is the x gather).
+
+constexpr bool op_needs_b(int OP) { return OP == OP_RESID || OP == OP_JACOBI || OP == OP_JACOBI_DOT || OP == OP_RESNORM; }
+constexpr bool op_needs_d(int OP) { return OP == OP_JACOBI || OP == OP_JACOBI_DOT; }
+constexpr bool op_needs_xi(int OP) { return OP == OP_JACOBI || OP == OP_JACOBI_DOT || OP == OP_SPMV_DOT; }
+constexpr bool op_reduces(int OP) { return OP == OP_SPMV_DOT || OP == OP_RESNORM || OP == OP_JACOBI_DOT; }
+
+struct RowOperands {
+    double bi = 0.0, di = 1.0, xi = 0.0;
+};
+
+template <int OP>
+__device__ __forceinline__ RowOperands load_row_operands(const CsrArgs &a, int row)
+{
+    RowOperands o;
+    if constexpr (op_needs_b(OP)) o.bi = a.b[row];
+    if constexpr (op_needs_d(OP)) o.di = a.d[row];
+    if constexpr (op_needs_xi(OP)) o.xi = a.x[row];
+    return o;
+}
+
+// stores the row result, returns this row's contribution to the fused reduction (if any)
+template <int OP>
+__device__ __forceinline__ double row_epilogue(const CsrArgs &a, int row, double sum, const RowOperands &o)
+{
+    if constexpr (OP == OP_SPMV) {
+        a.y[row] = sum;
+    } else if constexpr (OP == OP_RESID) {
+        a.y[row] = 1.0 * o.bi + (-1.0) * sum;
+    } else if constexpr (OP == OP_JACOBI || OP == OP_JACOBI_DOT) {
+        const double h = 1.0 * o.bi + (-1.0) * sum;
+        const double xn = o.xi + a.omega * h / o.di;
+        a.y[row] = xn;
+        if constexpr (OP == OP_JACOBI_DOT) return xn * o.bi;
+    } else if constexpr (OP == OP_ADD) {
+        a.y[row] = sum + a.y[row];
+    } else if constexpr (OP == OP_SPMV_DOT) {
+        a.y[row] = sum;
+        return o.xi * sum;
+    } else if constexpr (OP == OP_RESNORM) {
+        const double h = sum + (-1.0) * o.bi;
+        return h * h;
+    }
+    return 0.0;
+}
+
+// Phase 1 of the stream kernels: products of entries [j0, j1) into prod[0 .. j1-j0), walked by
+// `nthr` threads with unit stride.  Loads are issued in batches of U independent requests per
+// thread (indices clamped into the run, so no load sits behind a branch) -- a wave keeps 2U-3U
+// loads in flight instead of one dependent col -> x chain at a time.
+// VEC: two entries per request through 16-B / 8-B loads at even indices (col/val carry kCsrPad
+// zeroed tail entries, so the pair stays in bounds).
+template <bool NT, bool VEC>
+__device__ __forceinline__ void stream_products(const int *__restrict__ col, const double *__restrict__ val,
+                                                const double *__restrict__ x, int j0, int j1, int t, int nthr,
+                                                double *__restrict__ prod)
+{
+    if (j1 <= j0) return;
+    if constexpr (VEC) {
+        constexpr int U = 2;
+        const int jb = j0 & ~1;
+        const int jlast = (j1 - 1) & ~1;  // last valid even pair index
+        for (int j = jb + 2 * t; j < j1; j += 2 * U * nthr) {
+            i2v c[U];
+            d2v v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int jj = j + 2 * u * nthr;
+                jj = jj < jlast ? jj : jlast;
+                if constexpr (NT) {
+                    c[u] = __builtin_nontemporal_load(reinterpret_cast<const i2v *>(col + jj));
+                    v[u] = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(val + jj));
+                } else {
+                    c[u] = *reinterpret_cast<const i2v *>(col + jj);
+                    v[u] = *reinterpret_cast<const d2v *>(val + jj);
+                }
+            }
+            double xa[U], xb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                xa[u] = x[c[u].x];
+                xb[u] = x[c[u].y];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int jj = j + 2 * u * nthr;
+                const double p0 = v[u].x * xa[u];
+                const double p1 = v[u].y * xb[u];
+                if (jj >= j0 && jj < j1) prod[jj - j0] = p0;
+                if (jj + 1 < j1) prod[jj + 1 - j0] = p1;
+            }
+        }
+    } else {
+        constexpr int U = 4;
+        const int jlast = j1 - 1;
+        for (int j = j0 + t; j < j1; j += U * nthr) {
+            int c[U];
+            double v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int jj = j + u * nthr;
+                jj = jj < jlast ? jj : jlast;
+                c[u] = ld_stream<NT>(col + jj);
+                v[u] = ld_stream<NT>(val + jj);
+            }
+            double xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[u] = x[c[u]];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int jj = j + u * nthr;
+                const double p = v[u] * xv[u];
+                if (jj < j1) prod[jj - j0] = p;
+            }
+        }
+    }
+}
+
+// Phase 2: add the products prod[s .. e) of one row in order.  LDS reads are issued eight at a
+// time (clamped index), the adds stay strictly sequential.
+__device__ __forceinline__ double row_sum_lds(const double *__restrict__ prod, int s, int e)
+{
+    double sum = 0.0;
+    for (int k = s; k < e; k += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kk = k + u < e ? k + u : e - 1;
+            t[u] = prod[kk];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum = (k + u < e) ? sum + t[u] : sum;
+    }
+    return sum;
+}
+
+template <int OP, bool NT, bool VEC>
+__global__ __launch_bounds__(kBlock) void csr_block_kernel(const int *__restrict__ rowblk, int nblk, int remap,
+                                                            const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                            const double *__restrict__ val, CsrArgs a)
 {
     __shared__ double prod[kStreamNnz];
     __shared__ double red[kBlock / 64];
-    const int bid = xcd_remap(blockIdx.x, nblk);
+    const int bid = remap ? xcd_remap(blockIdx.x, nblk, remap) : blockIdx.x;
     if (bid >= nblk) return;  // whole workgroup leaves together
     const int tid = threadIdx.x;
     const int r0 = rowblk[bid], r1 = rowblk[bid + 1];
@@ -88,65 +248,227 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(const int *__restric
     const int j0 = rowptr[r0], j1 = rowptr[r1];
     const double *__restrict__ x = a.x;
 
+    // row operands first: their latency hides under the product stream
+    const bool has_row = tid < nrows;
+    const int row = r0 + tid;
+    int s = 0, e = 0;
+    RowOperands o;
+    if (has_row) {
+        s = rowptr[row] - j0;
+        e = rowptr[row + 1] - j0;
+        o = load_row_operands<OP>(a, row);
+    }
+
     double sum = 0.0;
-    int row = -1;
-    if (nrows == 1 && j1 - j0 > kStreamNnz) {
+    bool store = has_row;
+    if (nrows == 1 && j1 - j0 > kStreamNnz) {  // one long row: strided partial sums, tree-combined
         double part = 0.0;
         for (int j = j0 + tid; j < j1; j += kBlock) part += ld_stream<NT>(val + j) * x[ld_stream<NT>(col + j)];
         part = block_sum(part, red);
         __syncthreads();
-        if (tid == 0) {
-            sum = part;
-            row = r0;
-        }
+        sum = part;
+        store = (tid == 0);
     } else {
-        for (int j = j0 + tid; j < j1; j += kBlock) prod[j - j0] = ld_stream<NT>(val + j) * x[ld_stream<NT>(col + j)];
+        stream_products<NT, VEC>(col, val, x, j0, j1, tid, kBlock, prod);
         __syncthreads();
-        if (tid < nrows) {
-            row = r0 + tid;
-            const int s = rowptr[row] - j0, e = rowptr[row + 1] - j0;
-            for (int k = s; k < e; ++k) sum += prod[k];
-        }
+        sum = row_sum_lds(prod, s, e);
     }
 
     double acc = 0.0;
-    if (row >= 0) {
-        if constexpr (OP == OP_SPMV) {
-            a.y[row] = sum;
-        } else if constexpr (OP == OP_RESID) {
-            a.y[row] = 1.0 * a.b[row] + (-1.0) * sum;
-        } else if constexpr (OP == OP_JACOBI || OP == OP_JACOBI_DOT) {
-            const double bi = a.b[row];
-            const double h = 1.0 * bi + (-1.0) * sum;
-            const double xn = x[row] + a.omega * h / a.d[row];
-            a.y[row] = xn;
-            if constexpr (OP == OP_JACOBI_DOT) acc = xn * bi;
-        } else if constexpr (OP == OP_ADD) {
-            a.y[row] = sum + a.y[row];
-        } else if constexpr (OP == OP_SPMV_DOT) {
-            a.y[row] = sum;
-            acc = x[row] * sum;
-        } else if constexpr (OP == OP_RESNORM) {
-            const double h = sum + (-1.0) * a.b[row];
-            acc = h * h;
-        }
-    }
-    if constexpr (OP == OP_SPMV_DOT || OP == OP_RESNORM || OP == OP_JACOBI_DOT) {
+    if (store) acc = row_epilogue<OP>(a, row, sum, o);
+    if constexpr (op_reduces(OP)) {
         __syncthreads();
         const double t = block_sum(acc, red);
         if (tid == 0) a.partial[bid] = t;
     }
 }
 
-template <int OP>
-void launch_csr_op(const DevCsr &A, const CsrArgs &a, bool fine, hipStream_t st)
+template <int OP, bool NT, bool VEC>
+__global__ __launch_bounds__(kBlock) void csr_wave_kernel(const int *__restrict__ waveblk, int nwblk, int ngroups, int remap,
+                                                           const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                           const double *__restrict__ val, CsrArgs a)
 {
-    if (A.nblk <= 0) return;
-    const int grid = ((A.nblk + 7) >> 3) << 3;
-    if (fine)
-        hipLaunchKernelGGL((csr_stream_kernel<OP, true>), dim3(grid), dim3(kBlock), 0, st, A.rowblk, A.nblk, A.rowptr, A.col, A.val, a);
-    else
-        hipLaunchKernelGGL((csr_stream_kernel<OP, false>), dim3(grid), dim3(kBlock), 0, st, A.rowblk, A.nblk, A.rowptr, A.col, A.val, a);
+    __shared__ double prod_all[kBlock / 64][kWaveNnz];
+    __shared__ double red[kBlock / 64];
+    const int gid = remap ? xcd_remap(blockIdx.x, ngroups, remap) : blockIdx.x;  // group of 4 wave-blocks
+    if (gid >= ngroups) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wb = gid * (kBlock / 64) + w;
+    double acc = 0.0;
+    if (wb < nwblk) {  // wave-uniform
+        double *__restrict__ prod = prod_all[w];
+        const int r0 = waveblk[wb], r1 = waveblk[wb + 1];
+        const int nrows = r1 - r0;
+        const int j0 = rowptr[r0], j1 = rowptr[r1];
+        const double *__restrict__ x = a.x;
+        const bool has_row = lane < nrows;
+        const int row = r0 + lane;
+        int s = 0, e = 0;
+        RowOperands o;
+        if (has_row) {
+            s = rowptr[row] - j0;
+            e = rowptr[row + 1] - j0;
+            o = load_row_operands<OP>(a, row);
+        }
+        double sum = 0.0;
+        bool store = has_row;
+        if (nrows == 1 && j1 - j0 > kWaveNnz) {
+            double part = 0.0;
+            for (int j = j0 + lane; j < j1; j += 64) part += ld_stream<NT>(val + j) * x[ld_stream<NT>(col + j)];
+            sum = wave_sum(part);
+            store = (lane == 0);
+        } else {
+            stream_products<NT, VEC>(col, val, x, j0, j1, lane, 64, prod);
+            // same wave wrote and reads: LDS executes a wave's accesses in order; the fence keeps
+            // the compiler from moving the reads above the writes
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            sum = row_sum_lds(prod, s, e);
+        }
+        if (store) acc = row_epilogue<OP>(a, row, sum, o);
+    }
+    if constexpr (op_reduces(OP)) {
+        const double t = block_sum(acc, red);
+        if (threadIdx.x == 0) a.partial[gid] = t;
+    }
+}
+
+// sliced ELL: slice = 64 consecutive rows, entry k of row r at slice_ptr[slice] + k*64 + (r & 63).
+// Padding entries hold (col = 0, val = 0) and are never added (k < len select), so the row sum is
+// the same sequence of additions as the CSR loop.  The slice width is wave-uniform: common widths
+// dispatch to a fully unrolled body whose L col loads, L val loads and L gathers are all issued
+// before the first add.
+template <int L, bool NT>
+__device__ __forceinline__ double sell_chunk(const int *__restrict__ cp, const double *__restrict__ vp,
+                                             const double *__restrict__ x, int k0, int len, double sum)
+{
+    int c[L];
+    double v[L], xv[L];
+#pragma unroll
+    for (int u = 0; u < L; ++u) {
+        c[u] = ld_stream<NT>(cp + (k0 + u) * 64);
+        v[u] = ld_stream<NT>(vp + (k0 + u) * 64);
+    }
+#pragma unroll
+    for (int u = 0; u < L; ++u) xv[u] = x[c[u]];
+#pragma unroll
+    for (int u = 0; u < L; ++u) {
+        const double t = v[u] * xv[u];
+        sum = (k0 + u < len) ? sum + t : sum;
+    }
+    return sum;
+}
+
+template <bool NT>
+__device__ __forceinline__ double sell_row(const int *__restrict__ cp, const double *__restrict__ vp,
+                                           const double *__restrict__ x, int slen, int len)
+{
+    double sum = 0.0;
+    int k = 0;
+    for (; k + 8 <= slen; k += 8) sum = sell_chunk<8, NT>(cp, vp, x, k, len, sum);
+    switch (slen - k) {  // wave-uniform
+    case 7: sum = sell_chunk<7, NT>(cp, vp, x, k, len, sum); break;
+    case 6: sum = sell_chunk<6, NT>(cp, vp, x, k, len, sum); break;
+    case 5: sum = sell_chunk<5, NT>(cp, vp, x, k, len, sum); break;
+    case 4: sum = sell_chunk<4, NT>(cp, vp, x, k, len, sum); break;
+    case 3: sum = sell_chunk<3, NT>(cp, vp, x, k, len, sum); break;
+    case 2: sum = sell_chunk<2, NT>(cp, vp, x, k, len, sum); break;
+    case 1: sum = sell_chunk<1, NT>(cp, vp, x, k, len, sum); break;
+    default: break;
+    }
+    return sum;
+}
+
+template <int OP, bool NT>
+__global__ __launch_bounds__(kBlock) void sell_kernel(int nrow, int nslice, int ngroups, int remap,
+                                                       const int *__restrict__ slice_ptr, const int *__restrict__ rowptr,
+                                                       const int *__restrict__ scol, const double *__restrict__ sval, CsrArgs a)
+{
+    __shared__ double red[kBlock / 64];
+    const int gid = remap ? xcd_remap(blockIdx.x, ngroups, remap) : blockIdx.x;
+    if (gid >= ngroups) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int sl = gid * (kBlock / 64) + w;
+    double acc = 0.0;
+    if (sl < nslice) {
+        const int row = sl * 64 + lane;
+        const bool has_row = row < nrow;
+        const int base = __builtin_amdgcn_readfirstlane(slice_ptr[sl]);
+        const int slen = (__builtin_amdgcn_readfirstlane(slice_ptr[sl + 1]) - base) >> 6;
+        int len = 0;
+        RowOperands o;
+        if (has_row) {
+            len = rowptr[row + 1] - rowptr[row];
+            o = load_row_operands<OP>(a, row);
+        }
+        const double sum = sell_row<NT>(scol + base + lane, sval + base + lane, a.x, slen, len);
+        if (has_row) acc = row_epilogue<OP>(a, row, sum, o);
+    }
+    if constexpr (op_reduces(OP)) {
+        const double t = block_sum(acc, red);
+        if (threadIdx.x == 0) a.partial[gid] = t;
+    }
+}
+
+KernelConfig g_cfg;
+
+template <int OP>
+int launch_csr_op(const DevCsr &A, const CsrArgs &a, bool fine, hipStream_t st)
+{
+    const KernelConfig &c = g_cfg;
+    bool nt = fine && c.nt;
+    int remap = c.remap;
+    if (c.auto_policy) {
+        // measured on MI355X (profiles/r01_remap_sweep.txt): operators far beyond the 256 MiB
+        // Infinity Cache stream best with non-temporal loads and all XCDs sweeping one
+        // neighbourhood (groups of 16 row blocks); operators a few times the cache size prefer
+        // one contiguous eighth per XCD; cache-resident operators additionally drop the nt hint.
+        const size_t bytes = (size_t)A.nnz * 12 + (size_t)A.nrow * 36;
+        if (bytes > (900u << 20)) {
+            nt = true;
+            remap = 16;
+        } else if (bytes > (200u << 20)) {
+            nt = true;
+            remap = 1;
+        } else {
+            nt = false;
+            remap = 1;
+        }
+    }
+    if (c.kind == 2 && A.sell_val) {
+        const int ngroups = (A.nslice + 3) / 4;
+        if (ngroups <= 0) return 0;
+        const int grid = remap_grid(ngroups, remap);
+        if (nt)
+            hipLaunchKernelGGL((sell_kernel<OP, true>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.nslice, ngroups, remap, A.slice_ptr, A.rowptr, A.sell_col, A.sell_val, a);
+        else
+            hipLaunchKernelGGL((sell_kernel<OP, false>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.nslice, ngroups, remap, A.slice_ptr, A.rowptr, A.sell_col, A.sell_val, a);
+        return ngroups;
+    }
+    if (c.kind == 1 && A.waveblk) {
+        const int ngroups = (A.nwblk + 3) / 4;
+        if (ngroups <= 0) return 0;
+        const int grid = remap_grid(ngroups, remap);
+#define SPARSH_LAUNCH_WAVE(NT_, VEC_) \
+    hipLaunchKernelGGL((csr_wave_kernel<OP, NT_, VEC_>), dim3(grid), dim3(kBlock), 0, st, A.waveblk, A.nwblk, ngroups, remap, A.rowptr, A.col, A.val, a)
+        if (nt && c.vec) SPARSH_LAUNCH_WAVE(true, true);
+        else if (nt) SPARSH_LAUNCH_WAVE(true, false);
+        else if (c.vec) SPARSH_LAUNCH_WAVE(false, true);
+        else SPARSH_LAUNCH_WAVE(false, false);
+#undef SPARSH_LAUNCH_WAVE
+        return ngroups;
+    }
+    if (A.nblk <= 0) return 0;
+    const int grid = remap_grid(A.nblk, remap);
+#define SPARSH_LAUNCH_BLOCK(NT_, VEC_) \
+    hipLaunchKernelGGL((csr_block_kernel<OP, NT_, VEC_>), dim3(grid), dim3(kBlock), 0, st, A.rowblk, A.nblk, remap, A.rowptr, A.col, A.val, a)
+    if (nt && c.vec) SPARSH_LAUNCH_BLOCK(true, true);
+    else if (nt) SPARSH_LAUNCH_BLOCK(true, false);
+    else if (c.vec) SPARSH_LAUNCH_BLOCK(false, true);
+    else SPARSH_LAUNCH_BLOCK(false, false);
+#undef SPARSH_LAUNCH_BLOCK
+    return A.nblk;
 }
 
 // ------------------------------------------------------------------ elementwise
@@ -421,17 +743,41 @@ int build_rowblocks(int nrow, const int *rowptr, int *out)
     return nb;
 }
 
-void launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool fine, hipStream_t st)
+KernelConfig &kernel_config() { return g_cfg; }
+
+int launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool fine, hipStream_t st)
 {
     switch (op) {
-    case OP_SPMV: launch_csr_op<OP_SPMV>(A, a, fine, st); break;
-    case OP_RESID: launch_csr_op<OP_RESID>(A, a, fine, st); break;
-    case OP_JACOBI: launch_csr_op<OP_JACOBI>(A, a, fine, st); break;
-    case OP_ADD: launch_csr_op<OP_ADD>(A, a, fine, st); break;
-    case OP_SPMV_DOT: launch_csr_op<OP_SPMV_DOT>(A, a, fine, st); break;
-    case OP_RESNORM: launch_csr_op<OP_RESNORM>(A, a, fine, st); break;
-    case OP_JACOBI_DOT: launch_csr_op<OP_JACOBI_DOT>(A, a, fine, st); break;
+    case OP_SPMV: return launch_csr_op<OP_SPMV>(A, a, fine, st);
+    case OP_RESID: return launch_csr_op<OP_RESID>(A, a, fine, st);
+    case OP_JACOBI: return launch_csr_op<OP_JACOBI>(A, a, fine, st);
+    case OP_ADD: return launch_csr_op<OP_ADD>(A, a, fine, st);
+    case OP_SPMV_DOT: return launch_csr_op<OP_SPMV_DOT>(A, a, fine, st);
+    case OP_RESNORM: return launch_csr_op<OP_RESNORM>(A, a, fine, st);
+    case OP_JACOBI_DOT: return launch_csr_op<OP_JACOBI_DOT>(A, a, fine, st);
     }
+    return 0;
+}
+
+int build_waveblocks(int nrow, const int *rowptr, int *out)
+{
+    int nb = 0;
+    out[0] = 0;
+    int r = 0;
+    while (r < nrow) {
+        int rows = 0;
+        long nnz = 0;
+        while (r + rows < nrow && rows < 64) {
+            const long len = (long)rowptr[r + rows + 1] - rowptr[r + rows];
+            if (rows > 0 && nnz + len > kWaveNnz) break;
+            nnz += len;
+            ++rows;
+            if (nnz > kWaveNnz) break;
+        }
+        r += rows;
+        out[++nb] = r;
+    }
+    return nb;
 }
 
 void launch_jacobi_zero(int n, const double *b, const double *d, double omega, double *x, hipStream_t st)

@@ -17,10 +17,33 @@ struct DevCsr {
     // it is a single long row
     int *rowblk = nullptr;
     int nblk = 0;
+    // wave-granular schedule: wave-block k owns rows [waveblk[k], waveblk[k+1]) (<= 64 rows,
+    // <= kWaveNnz products unless it is a single long row)
+    int *waveblk = nullptr;
+    int nwblk = 0;
+    // optional sliced-ELL mirror (slices of 64 rows, column-major inside a slice) for operators
+    // with near-uniform row length: lane = row, every access of a wave is one contiguous segment
+    int nslice = 0;
+    int *slice_ptr = nullptr;   // nslice+1 offsets (in entries) into sell_col / sell_val
+    int *sell_col = nullptr;
+    double *sell_val = nullptr;
+    long sell_entries = 0;
 };
+
+// run-time choice of the SpMV-type kernel family (A/B measurements; defaults = the fastest measured)
+struct KernelConfig {
+    int kind = 2;       // 0 workgroup CSR-stream, 1 wave CSR-stream, 2 sliced-ELL where available (else 0)
+    bool vec = true;    // phase 1 reads two entries per lane (16-B val / 8-B col loads)
+    bool auto_policy = true;  // choose nt / remap per operator from its size (overrides the two below)
+    bool nt = true;     // non-temporal loads for the matrix stream of large operators
+    int remap = 1;      // 0 none, 1 XCD x owns the x-th contiguous eighth, G>1 groups of G row blocks dealt round-robin to XCDs
+};
+KernelConfig &kernel_config();
 
 constexpr int kBlock = 256;       // threads per workgroup (4 waves)
 constexpr int kStreamNnz = 2048;  // products staged in LDS per workgroup (16 KiB)
+constexpr int kWaveNnz = 512;     // products staged in LDS per wave (4 KiB) in the wave-granular kernel
+constexpr int kCsrPad = 4;        // zeroed entries appended to col/val so paired loads stay in bounds
 constexpr int kMaxPartials = 1 << 20;
 
 // epilogue selector of the CSR-stream kernel: what happens to the row sum s_i = (A x)_i
@@ -45,8 +68,10 @@ struct CsrArgs {
 
 // host-side builder of the row-block schedule (returns number of blocks; out sized nrow+1 max)
 int build_rowblocks(int nrow, const int *rowptr, int *out);
+int build_waveblocks(int nrow, const int *rowptr, int *out);
 
-void launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool fine, hipStream_t st);
+// returns the number of per-workgroup partial sums the launch writes (reducing ops)
+int launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool fine, hipStream_t st);
 
 // x_i = omega*b_i/d_i : first Jacobi sweep from a zero guess (bitwise equal to the full sweep)
 void launch_jacobi_zero(int n, const double *b, const double *d, double omega, double *x, hipStream_t st);

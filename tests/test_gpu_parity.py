@@ -68,6 +68,45 @@ def test_kernels_bitwise(case):
     assert np.linalg.norm(xg - xo) <= 1e-10 * np.linalg.norm(xo)
 
 
+KERNEL_CONFIGS = [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0)]
+
+
+@pytest.mark.parametrize("kind,vec", KERNEL_CONFIGS)
+def test_kernel_families_bitwise(case, kind, vec):
+    """Every SpMV-type kernel family (workgroup / wave CSR-stream, scalar / paired loads, sliced
+    ELL) must reproduce the oracle bit for bit, including the fused reductions' consumers."""
+    name, A, O, H = case
+    rng = np.random.default_rng(17)
+    try:
+        for nt, remap in ((1, 1), (0, 0), (1, 16), (-1, -1)):
+            sa.set_kernel_config(kind=kind, vec=vec, nt=nt, remap=remap)
+            for l in range(A.nlevels):
+                n = A.level_info(l)["nrow"]
+                x = rng.standard_normal(n)
+                b = rng.standard_normal(n)
+                Ol = H.A(l)
+                assert np.array_equal(A.op_spmv(l, x), oracle.spmv(Ol, x)), f"spmv level {l}"
+                assert np.array_equal(A.op_residual(l, b, x), oracle.store_residual(Ol, b, x)), f"residual level {l}"
+                assert np.array_equal(A.op_jacobi(l, b, x, 3), oracle.jacobi(Ol, b, x, 2)), f"jacobi level {l}"
+                rn = A.op_resnorm(l, b, x)
+                assert abs(rn - oracle.residual(Ol, b, x)) <= 1e-12 * rn
+                if l + 1 < A.nlevels:
+                    nc = A.level_info(l + 1)["nrow"]
+                    xc = rng.standard_normal(nc)
+                    assert np.array_equal(A.op_restrict(l, x), oracle.transfer_residual(H.P(l), x))
+                    assert np.array_equal(A.op_prolong(l, xc, x), oracle.transfer_solution(H.P(l), xc, x))
+        # whole solve through this family
+        nrow = A.nrow
+        bb = np.ones(nrow)
+        xx = np.zeros(nrow)
+        h, rc = A.solve("pcg", bb, xx)
+        xo, ho = oracle.solve("pcg", O, bb)
+        _hist_ok(h, ho)
+        assert np.linalg.norm(xx - xo) <= 1e-8 * np.linalg.norm(xo)
+    finally:
+        sa.set_kernel_config()
+
+
 def test_blas1(case):
     _, A, _, _ = case
     rng = np.random.default_rng(8)

@@ -18,9 +18,50 @@ def main():
     ap.add_argument("--dim", type=int, default=3)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--cfg", type=int, nargs=4, default=None, metavar=("KIND", "VEC", "NT", "REMAP"))
+    ap.add_argument("--remaps", type=int, nargs="*", default=None, help="sweep XCD remap modes for the Jacobi kernel")
+    ap.add_argument("--variants", action="store_true", help="A/B all kernel families (interleaved rounds, one process)")
+    ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--vlevels", type=int, nargs="*", default=[0, 2, 4])
     a = ap.parse_args()
     rp, ci, v = problems.poisson3d(a.n) if a.dim == 3 else problems.poisson2d(a.n)
     A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, print_solve=0))
+    if a.cfg:
+        sa.set_kernel_config(*a.cfg)
+    if a.remaps:
+        print(f"{'config':28s} {'op':8s} {'lvl':>3s} {'us':>9s} {'GB/s':>8s} {'frac8T':>7s}")
+        for rnd in range(a.rounds):
+            for (k, v) in ((2, 0), (0, 1)):
+                for nt in (1, 0):
+                    for rm in a.remaps:
+                        sa.set_kernel_config(kind=k, vec=v, nt=nt, remap=rm)
+                        for l in a.vlevels:
+                            if l >= A.nlevels:
+                                continue
+                            i = A.level_info(l)
+                            n, nnz = i["nrow"], i["nnz"]
+                            sec = A.bench_op("jacobi", l, a.reps)
+                            gbs = (12 * nnz + 36 * n) / sec / 1e9
+                            print(f"kind={k} vec={v} nt={nt} remap={rm:<5d} r{rnd:<2d} jacobi   {l:3d} {sec * 1e6:9.1f} {gbs:8.1f} {gbs / 8000:7.3f}", flush=True)
+        sa.set_kernel_config()
+        return
+    if a.variants:
+        print(f"{'config':28s} {'op':8s} {'lvl':>3s} {'us':>9s} {'GB/s':>8s} {'frac8T':>7s}")
+        cfgs = [(k, v, nt, rm) for k in (0, 1, 2) for v in ((0, 1) if k < 2 else (0,)) for nt in (1, 0) for rm in (1, 0)]
+        for rnd in range(a.rounds):
+            for (k, v, nt, rm) in cfgs:
+                sa.set_kernel_config(kind=k, vec=v, nt=nt, remap=rm)
+                for l in a.vlevels:
+                    if l >= A.nlevels:
+                        continue
+                    i = A.level_info(l)
+                    n, nnz = i["nrow"], i["nnz"]
+                    for op, nbytes in (("jacobi", 12 * nnz + 36 * n), ("spmv", 12 * nnz + 20 * n)):
+                        sec = A.bench_op(op, l, a.reps)
+                        gbs = nbytes / sec / 1e9
+                        print(f"kind={k} vec={v} nt={nt} remap={rm} r{rnd:<3d} {op:8s} {l:3d} {sec * 1e6:9.1f} {gbs:8.1f} {gbs / 8000:7.3f}", flush=True)
+        sa.set_kernel_config()
+        return
     print(f"{'op':10s} {'lvl':>3s} {'rows':>10s} {'nnz':>10s} {'us':>9s} {'GB/s':>8s} {'frac8T':>7s}")
     for l in range(min(a.levels, A.nlevels)):
         i = A.level_info(l)
