@@ -151,7 +151,7 @@ def main():
         roof = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "kernel": "csr_stream_kernel<OP_JACOBI> (finest level)", "launches": pr["launches"],
+            "kernel": "sell_kernel<OP_JACOBI=2, NT=true, TAG=1> (fused Jacobi sweep, finest level)", "launches": pr["launches"],
             "avg_us": round(avg * 1e6, 2), "bytes_per_launch": jac_bytes,
         }
 

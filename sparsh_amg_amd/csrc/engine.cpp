@@ -21,7 +21,6 @@
 namespace sparsh {
 
 namespace {
-constexpr size_t kFineBytes = 96u << 20;  // operators above this stream with non-temporal loads
 constexpr int kProfEvents = 8192;
 }  // namespace
 
@@ -195,7 +194,7 @@ int Engine::setup(const sparsh_params &p)
         DevLevel &d = lev_[l];
         d.n = h.A.nrow;
         if (!upload_csr(*this, h.A, d.A, true)) return SPARSH_ENODEV;
-        d.fine = (size_t)d.A.nnz * 12 + (size_t)d.n * 4 > kFineBytes;
+        d.fine = (l == 0);  // finest level: separately named kernel instances (profiling)
         d.diag = upload(*this, h.diag.data(), (size_t)d.n);
         d.x = static_cast<double *>(dalloc((size_t)d.n * 8));
         d.x2 = static_cast<double *>(dalloc((size_t)d.n * 8));

@@ -21,7 +21,7 @@ struct DevLevel {
     double *x = nullptr, *x2 = nullptr;  // ping-pong solution buffers (Jacobi reads old, writes new)
     double *b = nullptr;                 // rhs of this level (level 0: points at the caller's vector)
     double *r = nullptr;                 // residual
-    bool fine = false;                   // operator larger than the on-die caches: stream with nt loads
+    bool fine = false;                   // finest level of the hierarchy
 };
 
 struct KrylovState {

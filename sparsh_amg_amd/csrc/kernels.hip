@@ -233,7 +233,9 @@ __device__ __forceinline__ double row_sum_lds(const double *__restrict__ prod, i
     return sum;
 }
 
-template <int OP, bool NT, bool VEC>
+// TAG: 1 for launches on the finest level.  Identical code; a distinct symbol lets profiler
+// summaries (rocprofv3 --stats) separate the dominant finest-level launches from coarse ones.
+template <int OP, bool NT, bool VEC, int TAG>
 __global__ __launch_bounds__(kBlock) void csr_block_kernel(const int *__restrict__ rowblk, int nblk, int remap,
                                                             const int *__restrict__ rowptr, const int *__restrict__ col,
                                                             const double *__restrict__ val, CsrArgs a)
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(const int *__restrict
     }
 }
 
-template <int OP, bool NT, bool VEC>
+template <int OP, bool NT, bool VEC, int TAG>
 __global__ __launch_bounds__(kBlock) void csr_wave_kernel(const int *__restrict__ waveblk, int nwblk, int ngroups, int remap,
                                                            const int *__restrict__ rowptr, const int *__restrict__ col,
                                                            const double *__restrict__ val, CsrArgs a)
@@ -380,7 +382,7 @@ __device__ __forceinline__ double sell_row(const int *__restrict__ cp, const dou
     return sum;
 }
 
-template <int OP, bool NT>
+template <int OP, bool NT, int TAG>
 __global__ __launch_bounds__(kBlock) void sell_kernel(int nrow, int nslice, int ngroups, int remap,
                                                        const int *__restrict__ slice_ptr, const int *__restrict__ rowptr,
                                                        const int *__restrict__ scol, const double *__restrict__ sval, CsrArgs a)
@@ -413,11 +415,50 @@ __global__ __launch_bounds__(kBlock) void sell_kernel(int nrow, int nslice, int 
 
 KernelConfig g_cfg;
 
-template <int OP>
-int launch_csr_op(const DevCsr &A, const CsrArgs &a, bool fine, hipStream_t st)
+template <int OP, int TAG>
+int launch_csr_tagged(const DevCsr &A, const CsrArgs &a, bool nt, int remap, hipStream_t st)
 {
     const KernelConfig &c = g_cfg;
-    bool nt = fine && c.nt;
+    if (c.kind == 2 && A.sell_val) {
+        const int ngroups = (A.nslice + 3) / 4;
+        if (ngroups <= 0) return 0;
+        const int grid = remap_grid(ngroups, remap);
+        if (nt)
+            hipLaunchKernelGGL((sell_kernel<OP, true, TAG>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.nslice, ngroups, remap, A.slice_ptr, A.rowptr, A.sell_col, A.sell_val, a);
+        else
+            hipLaunchKernelGGL((sell_kernel<OP, false, TAG>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.nslice, ngroups, remap, A.slice_ptr, A.rowptr, A.sell_col, A.sell_val, a);
+        return ngroups;
+    }
+    if (c.kind == 1 && A.waveblk) {
+        const int ngroups = (A.nwblk + 3) / 4;
+        if (ngroups <= 0) return 0;
+        const int grid = remap_grid(ngroups, remap);
+#define SPARSH_LAUNCH_WAVE(NT_, VEC_) \
+    hipLaunchKernelGGL((csr_wave_kernel<OP, NT_, VEC_, TAG>), dim3(grid), dim3(kBlock), 0, st, A.waveblk, A.nwblk, ngroups, remap, A.rowptr, A.col, A.val, a)
+        if (nt && c.vec) SPARSH_LAUNCH_WAVE(true, true);
+        else if (nt) SPARSH_LAUNCH_WAVE(true, false);
+        else if (c.vec) SPARSH_LAUNCH_WAVE(false, true);
+        else SPARSH_LAUNCH_WAVE(false, false);
+#undef SPARSH_LAUNCH_WAVE
+        return ngroups;
+    }
+    if (A.nblk <= 0) return 0;
+    const int grid = remap_grid(A.nblk, remap);
+#define SPARSH_LAUNCH_BLOCK(NT_, VEC_) \
+    hipLaunchKernelGGL((csr_block_kernel<OP, NT_, VEC_, TAG>), dim3(grid), dim3(kBlock), 0, st, A.rowblk, A.nblk, remap, A.rowptr, A.col, A.val, a)
+    if (nt && c.vec) SPARSH_LAUNCH_BLOCK(true, true);
+    else if (nt) SPARSH_LAUNCH_BLOCK(true, false);
+    else if (c.vec) SPARSH_LAUNCH_BLOCK(false, true);
+    else SPARSH_LAUNCH_BLOCK(false, false);
+#undef SPARSH_LAUNCH_BLOCK
+    return A.nblk;
+}
+
+template <int OP>
+int launch_csr_op(const DevCsr &A, const CsrArgs &a, bool finest, hipStream_t st)
+{
+    const KernelConfig &c = g_cfg;
+    bool nt = c.nt;
     int remap = c.remap;
     if (c.auto_policy) {
         // measured on MI355X (profiles/r01_remap_sweep.txt): operators far beyond the 256 MiB
@@ -436,39 +477,7 @@ int launch_csr_op(const DevCsr &A, const CsrArgs &a, bool fine, hipStream_t st)
             remap = 1;
         }
     }
-    if (c.kind == 2 && A.sell_val) {
-        const int ngroups = (A.nslice + 3) / 4;
-        if (ngroups <= 0) return 0;
-        const int grid = remap_grid(ngroups, remap);
-        if (nt)
-            hipLaunchKernelGGL((sell_kernel<OP, true>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.nslice, ngroups, remap, A.slice_ptr, A.rowptr, A.sell_col, A.sell_val, a);
-        else
-            hipLaunchKernelGGL((sell_kernel<OP, false>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.nslice, ngroups, remap, A.slice_ptr, A.rowptr, A.sell_col, A.sell_val, a);
-        return ngroups;
-    }
-    if (c.kind == 1 && A.waveblk) {
-        const int ngroups = (A.nwblk + 3) / 4;
-        if (ngroups <= 0) return 0;
-        const int grid = remap_grid(ngroups, remap);
-#define SPARSH_LAUNCH_WAVE(NT_, VEC_) \
-    hipLaunchKernelGGL((csr_wave_kernel<OP, NT_, VEC_>), dim3(grid), dim3(kBlock), 0, st, A.waveblk, A.nwblk, ngroups, remap, A.rowptr, A.col, A.val, a)
-        if (nt && c.vec) SPARSH_LAUNCH_WAVE(true, true);
-        else if (nt) SPARSH_LAUNCH_WAVE(true, false);
-        else if (c.vec) SPARSH_LAUNCH_WAVE(false, true);
-        else SPARSH_LAUNCH_WAVE(false, false);
-#undef SPARSH_LAUNCH_WAVE
-        return ngroups;
-    }
-    if (A.nblk <= 0) return 0;
-    const int grid = remap_grid(A.nblk, remap);
-#define SPARSH_LAUNCH_BLOCK(NT_, VEC_) \
-    hipLaunchKernelGGL((csr_block_kernel<OP, NT_, VEC_>), dim3(grid), dim3(kBlock), 0, st, A.rowblk, A.nblk, remap, A.rowptr, A.col, A.val, a)
-    if (nt && c.vec) SPARSH_LAUNCH_BLOCK(true, true);
-    else if (nt) SPARSH_LAUNCH_BLOCK(true, false);
-    else if (c.vec) SPARSH_LAUNCH_BLOCK(false, true);
-    else SPARSH_LAUNCH_BLOCK(false, false);
-#undef SPARSH_LAUNCH_BLOCK
-    return A.nblk;
+    return finest ? launch_csr_tagged<OP, 1>(A, a, nt, remap, st) : launch_csr_tagged<OP, 0>(A, a, nt, remap, st);
 }
 
 // ------------------------------------------------------------------ elementwise
@@ -745,16 +754,16 @@ int build_rowblocks(int nrow, const int *rowptr, int *out)
 
 KernelConfig &kernel_config() { return g_cfg; }
 
-int launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool fine, hipStream_t st)
+int launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool finest, hipStream_t st)
 {
     switch (op) {
-    case OP_SPMV: return launch_csr_op<OP_SPMV>(A, a, fine, st);
-    case OP_RESID: return launch_csr_op<OP_RESID>(A, a, fine, st);
-    case OP_JACOBI: return launch_csr_op<OP_JACOBI>(A, a, fine, st);
-    case OP_ADD: return launch_csr_op<OP_ADD>(A, a, fine, st);
-    case OP_SPMV_DOT: return launch_csr_op<OP_SPMV_DOT>(A, a, fine, st);
-    case OP_RESNORM: return launch_csr_op<OP_RESNORM>(A, a, fine, st);
-    case OP_JACOBI_DOT: return launch_csr_op<OP_JACOBI_DOT>(A, a, fine, st);
+    case OP_SPMV: return launch_csr_op<OP_SPMV>(A, a, finest, st);
+    case OP_RESID: return launch_csr_op<OP_RESID>(A, a, finest, st);
+    case OP_JACOBI: return launch_csr_op<OP_JACOBI>(A, a, finest, st);
+    case OP_ADD: return launch_csr_op<OP_ADD>(A, a, finest, st);
+    case OP_SPMV_DOT: return launch_csr_op<OP_SPMV_DOT>(A, a, finest, st);
+    case OP_RESNORM: return launch_csr_op<OP_RESNORM>(A, a, finest, st);
+    case OP_JACOBI_DOT: return launch_csr_op<OP_JACOBI_DOT>(A, a, finest, st);
     }
     return 0;
 }

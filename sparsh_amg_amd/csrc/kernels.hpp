@@ -35,7 +35,7 @@ struct KernelConfig {
     int kind = 2;       // 0 workgroup CSR-stream, 1 wave CSR-stream, 2 sliced-ELL where available (else 0)
     bool vec = true;    // phase 1 reads two entries per lane (16-B val / 8-B col loads)
     bool auto_policy = true;  // choose nt / remap per operator from its size (overrides the two below)
-    bool nt = true;     // non-temporal loads for the matrix stream of large operators
+    bool nt = true;     // non-temporal loads for the matrix stream
     int remap = 1;      // 0 none, 1 XCD x owns the x-th contiguous eighth, G>1 groups of G row blocks dealt round-robin to XCDs
 };
 KernelConfig &kernel_config();
@@ -71,7 +71,8 @@ int build_rowblocks(int nrow, const int *rowptr, int *out);
 int build_waveblocks(int nrow, const int *rowptr, int *out);
 
 // returns the number of per-workgroup partial sums the launch writes (reducing ops)
-int launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool fine, hipStream_t st);
+// `finest`: launch on the finest level (selects a separately named kernel instance for profilers)
+int launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool finest, hipStream_t st);
 
 // x_i = omega*b_i/d_i : first Jacobi sweep from a zero guess (bitwise equal to the full sweep)
 void launch_jacobi_zero(int n, const double *b, const double *d, double omega, double *x, hipStream_t st);
