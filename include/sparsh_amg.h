@@ -62,6 +62,8 @@ typedef struct sparsh_params {
     int check_every;    /* Krylov/AMG loops read the residual norm back every k iterations
                            (1 = reference behaviour: every iteration)                          */
     int use_graph;      /* capture one V-cycle into a hipGraph and replay it   [SPARSH_GRAPH]   */
+    int replicate_rows; /* multi-GPU: levels with at most this many rows are held and computed by every
+                           rank (no halo exchange below that size)            [SPARSH_REPLICATE_ROWS] */
 } sparsh_params;
 
 typedef struct sparsh_handle_s *sparsh_handle;
@@ -174,6 +176,34 @@ int sparsh_sync(sparsh_handle h);
  * out[0] = launches, out[1] = total seconds, out[2] = rows, out[3] = nnz of that level. */
 int sparsh_profile(sparsh_handle h, int enable);
 int sparsh_profile_read(sparsh_handle h, double *out4);
+
+/* ---- multi-GPU (new design; the reference is single-GPU).  One process per GPU.  Every level
+ * above params.replicate_rows is split into contiguous row blocks, one per rank; before each
+ * SpMV-type kernel the neighbours' boundary entries of the input vector travel over RCCL (grouped
+ * ncclSend/ncclRecv, xGMI); fused scalars are all-reduced; smaller levels and the coarsest solve
+ * are computed by every rank.  All ranks run the same host setup on the whole matrix.
+ * Bootstrap: rank 0 calls sparsh_comm_unique_id, the 128 bytes travel by any side channel
+ * (e.g. a torch.distributed broadcast), every rank calls sparsh_comm_init_rccl BEFORE
+ * sparsh_setup.  After setup, vectors passed to the *_dev entry points are the rank's own block
+ * [lo, hi) of level 0 (sparsh_local_range). */
+int sparsh_comm_unique_id(char id128[128]);
+int sparsh_comm_init_rccl(sparsh_handle h, const char id128[128], int rank, int nranks);
+int sparsh_local_range(sparsh_handle h, int level, int *lo, int *hi, int *replicated);
+
+/* In-process transport for tests: nranks handles driven by nranks host threads on one GPU. */
+int sparsh_comm_group_create(int nranks, void **group);
+void sparsh_comm_group_destroy(void *group);
+int sparsh_comm_init_group(sparsh_handle h, void *group, int rank);
+
+/* Host-only planning query (after sparsh_setup_host): the block of operator `which` (0 A_l, 1 P_l,
+ * 2 R_l) that `rank` of `nranks` holds when every level is partitioned, with its halo plan.
+ * sizes8 = {rows, nnz, own input entries, halo entries, send segments, recv segments,
+ * packed send entries, first global row}.  The _get call copies the arrays of the last query:
+ * local CSR (columns renumbered: own entries first, then halo), global index of every halo
+ * entry, indices to pack, and (peer, offset, count) triples of the send / receive segments. */
+int sparsh_dist_local_op(sparsh_handle h, int level, int which, int rank, int nranks, int *sizes8);
+int sparsh_dist_local_op_get(sparsh_handle h, int *rowptr, int *col, double *val, int *halo_global, int *send_idx, int *send_segs3,
+                             int *recv_segs3);
 
 #ifdef __cplusplus
 }

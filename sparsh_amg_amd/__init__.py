@@ -55,6 +55,7 @@ class Params(C.Structure):
         ("print_solve", C.c_int),
         ("check_every", C.c_int),
         ("use_graph", C.c_int),
+        ("replicate_rows", C.c_int),
     ]
 
 
@@ -87,6 +88,14 @@ def _load():
         "sparsh_vcycle": (C.c_int, [H, c_dbl_p, c_dbl_p, C.c_int, c_dbl_p, C.c_int, c_int_p]),
         "sparsh_solve": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, C.c_int, c_int_p]),
         "sparsh_solve_dev": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_int, c_dbl_p, C.c_int, c_int_p, c_dbl_p]),
+        "sparsh_comm_unique_id": (C.c_int, [C.c_char_p]),
+        "sparsh_comm_init_rccl": (C.c_int, [H, C.c_char_p, C.c_int, C.c_int]),
+        "sparsh_local_range": (C.c_int, [H, C.c_int, c_int_p, c_int_p, c_int_p]),
+        "sparsh_comm_group_create": (C.c_int, [C.c_int, P(C.c_void_p)]),
+        "sparsh_comm_group_destroy": (None, [C.c_void_p]),
+        "sparsh_comm_init_group": (C.c_int, [H, C.c_void_p, C.c_int]),
+        "sparsh_dist_local_op": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p]),
+        "sparsh_dist_local_op_get": (C.c_int, [H, c_int_p, c_int_p, c_dbl_p, c_int_p, c_int_p, c_int_p, c_int_p]),
         "sparsh_krylov_init_dev": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p]),
         "sparsh_krylov_step_dev": (C.c_int, [H, C.c_int, c_int_p, c_dbl_p]),
         "sparsh_krylov_history": (C.c_int, [H, c_dbl_p, C.c_int, c_int_p]),
@@ -146,6 +155,22 @@ def default_params(**kw) -> Params:
 def set_kernel_config(kind=2, vec=True, nt=-1, remap=-1):
     """Select the SpMV-type kernel family (process-wide); see sparsh_set_kernel_config."""
     _check(lib.sparsh_set_kernel_config(int(kind), int(vec), int(nt), int(remap)))
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    _check(lib.sparsh_comm_unique_id(buf))
+    return buf.raw
+
+
+def comm_group_create(nranks: int):
+    g = C.c_void_p()
+    _check(lib.sparsh_comm_group_create(nranks, C.byref(g)))
+    return g
+
+
+def comm_group_destroy(g):
+    lib.sparsh_comm_group_destroy(g)
 
 
 def device_count() -> int:
@@ -236,6 +261,42 @@ class sp_matrix_mg:
         inv = np.zeros((n, n))
         _check(lib.sparsh_coarse_inverse(self._h, _dp(inv)))
         return inv
+
+    # -- multi-GPU -------------------------------------------------------------------------
+    def comm_init_rccl(self, unique_id: bytes, rank: int, nranks: int):
+        """Install the RCCL transport (call before setup)."""
+        assert len(unique_id) == 128
+        _check(lib.sparsh_comm_init_rccl(self._h, unique_id, rank, nranks))
+
+    def comm_init_group(self, group, rank: int):
+        """Install the in-process test transport (call before setup)."""
+        _check(lib.sparsh_comm_init_group(self._h, group, rank))
+
+    def local_range(self, level=0):
+        lo, hi, rep = C.c_int(), C.c_int(), C.c_int()
+        _check(lib.sparsh_local_range(self._h, level, C.byref(lo), C.byref(hi), C.byref(rep)))
+        return lo.value, hi.value, bool(rep.value)
+
+    def dist_local_op(self, level, which, rank, nranks):
+        """Host-only planning query: (scipy local matrix, plan dict) of operator A/P/R."""
+        import scipy.sparse as sp
+
+        w = {"A": 0, "P": 1, "R": 2}[which]
+        sz = (C.c_int * 8)()
+        _check(lib.sparsh_dist_local_op(self._h, level, w, rank, nranks, sz))
+        nrow, nnz, nloc, nhalo, nss, nrs, nsend, row0 = list(sz)
+        rp = np.zeros(nrow + 1, dtype=np.int32)
+        ci = np.zeros(max(nnz, 1), dtype=np.int32)
+        v = np.zeros(max(nnz, 1))
+        hg = np.zeros(max(nhalo, 1), dtype=np.int32)
+        si = np.zeros(max(nsend, 1), dtype=np.int32)
+        ss = np.zeros(max(3 * nss, 1), dtype=np.int32)
+        rs = np.zeros(max(3 * nrs, 1), dtype=np.int32)
+        _check(lib.sparsh_dist_local_op_get(self._h, _ip(rp), _ip(ci), _dp(v), _ip(hg), _ip(si), _ip(ss), _ip(rs)))
+        M = sp.csr_matrix((v[:nnz], ci[:nnz], rp), shape=(nrow, nloc + nhalo))
+        plan = dict(nloc=nloc, nhalo=nhalo, row0=row0, halo_global=hg[:nhalo], send_idx=si[:nsend],
+                    send=ss[: 3 * nss].reshape(-1, 3), recv=rs[: 3 * nrs].reshape(-1, 3))
+        return M, plan
 
     # -- solvers (host vectors) ------------------------------------------------------------
     def vcycle(self, b, x, iterations=-1, hist_cap=8192):

@@ -17,6 +17,7 @@ using namespace sparsh;
 
 struct sparsh_handle_s {
     std::unique_ptr<Engine> eng;
+    LocalOp cached_op;  // last sparsh_dist_local_op result
 };
 
 namespace {
@@ -109,6 +110,7 @@ void sparsh_default_params(sparsh_params *p)
     p->print_solve = pr;
     p->check_every = 1;
     p->use_graph = env_int("SPARSH_GRAPH", 0);
+    p->replicate_rows = env_int("SPARSH_REPLICATE_ROWS", 200000);
 }
 
 int sparsh_create_csr(int nrow, int ncol, const int *rowptr, const int *colindex, const double *val, sparsh_handle *out)
@@ -217,7 +219,7 @@ int sparsh_vcycle(sparsh_handle h, const double *b, double *x, int iterations, d
 {
     REQUIRE_READY(h);
     Engine &E = *h->eng;
-    const size_t n = (size_t)E.n0();
+    const size_t n = (size_t)E.local_n0();  // multi-GPU: this rank's block of level 0
     DBuf db(E, n, b), dx(E, n, x);
     if (!db.p || !dx.p) return fail(SPARSH_ENODEV, E.error);
     int rc = E.amg_solve_dev(db.p, dx.p, iterations, hist, hist_cap, ncycles);
@@ -230,7 +232,7 @@ int sparsh_solve(sparsh_handle h, int method, const double *b, double *x, double
 {
     REQUIRE_READY(h);
     Engine &E = *h->eng;
-    const size_t n = (size_t)E.n0();
+    const size_t n = (size_t)E.local_n0();  // multi-GPU: this rank's block of level 0
     DBuf db(E, n, b), dx(E, n, x);
     if (!db.p || !dx.p) return fail(SPARSH_ENODEV, E.error);
     int rc = E.solve_dev(method, db.p, dx.p, 0, hist, hist_cap, iters, nullptr);
@@ -246,6 +248,112 @@ int sparsh_solve_dev(sparsh_handle h, int method, const double *b_dev, double *x
     int rc = h->eng->solve_dev(method, b_dev, x_dev, max_iters, hist, hist_cap, iters, seconds);
     if (rc != SPARSH_OK) return fail(rc, h->eng->error);
     return rc;
+}
+
+// ---- multi-GPU ----
+
+int sparsh_comm_unique_id(char id128[128])
+{
+    std::string err;
+    if (!rccl_unique_id(id128, err)) return fail(SPARSH_ECOMM, err);
+    return SPARSH_OK;
+}
+
+int sparsh_comm_init_rccl(sparsh_handle h, const char id128[128], int rank, int nranks)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    if (rank < 0 || rank >= nranks) return fail(SPARSH_EINVAL, "rank out of range");
+    std::string err;
+    auto c = make_rccl_comm(id128, rank, nranks, err);
+    if (!c) return fail(SPARSH_ECOMM, err);
+    h->eng->set_comm(std::move(c));
+    return SPARSH_OK;
+}
+
+int sparsh_comm_group_create(int nranks, void **group)
+{
+    if (nranks < 1 || !group) return fail(SPARSH_EINVAL, "bad arguments");
+    *group = thread_group_create(nranks);
+    return SPARSH_OK;
+}
+
+void sparsh_comm_group_destroy(void *group) { thread_group_destroy(static_cast<ThreadGroup *>(group)); }
+
+int sparsh_comm_init_group(sparsh_handle h, void *group, int rank)
+{
+    if (!h || !h->eng || !group) return fail(SPARSH_EINVAL, "bad arguments");
+    h->eng->set_comm(make_thread_comm(static_cast<ThreadGroup *>(group), rank));
+    return SPARSH_OK;
+}
+
+int sparsh_local_range(sparsh_handle h, int level, int *lo, int *hi, int *replicated)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    Engine &E = *h->eng;
+    const Partition &p = E.partition(level);
+    const int r = E.comm() ? E.comm()->rank : 0;
+    if (lo) *lo = p.replicated ? 0 : p.lo(r);
+    if (hi) *hi = p.replicated ? p.n : p.hi(r);
+    if (replicated) *replicated = p.replicated ? 1 : 0;
+    return SPARSH_OK;
+}
+
+// Host-only planning query (needs sparsh_setup_host): the part of operator `which` (0 A_l, 1 P_l,
+// 2 R_l) that `rank` of `nranks` holds when no level is replicated, and its halo plan.
+int sparsh_dist_local_op(sparsh_handle h, int level, int which, int rank, int nranks, int *sizes8)
+{
+    REQUIRE_HOST(h);
+    REQUIRE_LEVEL(h, level);
+    if (nranks < 1 || rank < 0 || rank >= nranks || which < 0 || which > 2) return fail(SPARSH_EINVAL, "bad arguments");
+    const HostHierarchy &H = h->eng->host();
+    const int nl = (int)H.levels.size();
+    if (which != 0 && level + 1 >= nl) return fail(SPARSH_EINVAL, "no coarser level");
+    std::vector<Partition> parts((size_t)nl);
+    for (int l = 0; l <= std::min(level + 1, nl - 1); ++l)
+        parts[l] = (l == 0) ? make_partition(H.levels[0].A.nrow, nranks) : coarse_partition(H.levels[l - 1].R, parts[l - 1]);
+    const HostLevel &L = H.levels[level];
+    if (which == 0)
+        h->cached_op = extract_local(L.A, parts[level], parts[level], rank);
+    else if (which == 1)
+        h->cached_op = extract_local(L.P, parts[level], parts[level + 1], rank);
+    else
+        h->cached_op = extract_local(L.R, parts[level + 1], parts[level], rank);
+    const LocalOp &o = h->cached_op;
+    const Partition &rowsP = (which == 2) ? parts[level + 1] : parts[level];
+    sizes8[0] = o.M.nrow;
+    sizes8[1] = o.M.nnz();
+    sizes8[2] = o.plan.nloc;
+    sizes8[3] = o.plan.nhalo;
+    sizes8[4] = (int)o.plan.send.size();
+    sizes8[5] = (int)o.plan.recv.size();
+    sizes8[6] = (int)o.plan.send_idx.size();
+    sizes8[7] = rowsP.lo(rank);
+    return SPARSH_OK;
+}
+
+int sparsh_dist_local_op_get(sparsh_handle h, int *rowptr, int *col, double *val, int *halo_global, int *send_idx, int *send_segs3,
+                             int *recv_segs3)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    const LocalOp &o = h->cached_op;
+    if (!o.M.rowptr) return fail(SPARSH_ESTATE, "call sparsh_dist_local_op first");
+    std::memcpy(rowptr, o.M.rowptr, sizeof(int) * ((size_t)o.M.nrow + 1));
+    std::memcpy(col, o.M.col, sizeof(int) * (size_t)o.M.nnz());
+    std::memcpy(val, o.M.val, sizeof(double) * (size_t)o.M.nnz());
+    std::copy(o.plan.halo_global.begin(), o.plan.halo_global.end(), halo_global);
+    std::copy(o.plan.send_idx.begin(), o.plan.send_idx.end(), send_idx);
+    for (size_t k = 0; k < o.plan.send.size(); ++k) {
+        send_segs3[3 * k] = o.plan.send[k].peer;
+        send_segs3[3 * k + 1] = o.plan.send[k].off;
+        send_segs3[3 * k + 2] = o.plan.send[k].cnt;
+    }
+    for (size_t k = 0; k < o.plan.recv.size(); ++k) {
+        recv_segs3[3 * k] = o.plan.recv[k].peer;
+        recv_segs3[3 * k + 1] = o.plan.recv[k].off;
+        recv_segs3[3 * k + 2] = o.plan.recv[k].cnt;
+    }
+    return SPARSH_OK;
 }
 
 int sparsh_krylov_init_dev(sparsh_handle h, int method, const double *b_dev, double *x_dev)

@@ -1,0 +1,52 @@
+// comm.hpp -- transport of the row-block partitioned solver.  One process per GPU in production
+// (RcclComm: RCCL over xGMI, bootstrapped from a 128-byte unique id any side channel can carry,
+// e.g. a torch.distributed broadcast); ThreadComm runs G virtual ranks inside one process on one
+// GPU for tests; SelfComm is the single-GPU no-op.
+#pragma once
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+
+#include "dist.hpp"
+
+namespace sparsh {
+
+// device-side image of a HaloPlan
+struct DevPlan {
+    int nloc = 0, nhalo = 0, nsend = 0;
+    int *send_idx = nullptr;   // device, nsend
+    double *sendbuf = nullptr; // device, nsend
+    std::vector<HaloSeg> recv, send;
+    bool empty() const { return nhalo == 0 && nsend == 0; }
+};
+
+class Comm {
+public:
+    virtual ~Comm() = default;
+    int rank = 0, size = 1;
+    // vec holds nloc own entries followed by room for nhalo received ones; sendbuf is already packed
+    virtual bool exchange(const DevPlan &p, double *vec, hipStream_t st) = 0;
+    // in-place sum over ranks of n doubles in device memory
+    virtual bool allreduce_sum(double *dev, int n, hipStream_t st) = 0;
+    // every rank contributes full[lo(rank) .. hi(rank)) of `part`; afterwards all ranks hold all of it
+    virtual bool allgather(double *full, const Partition &part, hipStream_t st) = 0;
+    virtual bool barrier(hipStream_t st) = 0;
+    std::string error;
+};
+
+std::unique_ptr<Comm> make_self_comm();
+
+// ---- RCCL ----
+bool rccl_unique_id(char out[128], std::string &err);
+std::unique_ptr<Comm> make_rccl_comm(const char id[128], int rank, int nranks, std::string &err);
+
+// ---- in-process thread group (tests) ----
+struct ThreadGroup;
+ThreadGroup *thread_group_create(int nranks);
+void thread_group_destroy(ThreadGroup *g);
+std::unique_ptr<Comm> make_thread_comm(ThreadGroup *g, int rank);
+
+}  // namespace sparsh

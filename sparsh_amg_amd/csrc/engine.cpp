@@ -165,6 +165,21 @@ int Engine::setup_host(const sparsh_params &p)
     return SPARSH_OK;
 }
 
+bool Engine::upload_plan(const HaloPlan &h, DevPlan &d)
+{
+    d.nloc = h.nloc;
+    d.nhalo = h.nhalo;
+    d.nsend = (int)h.send_idx.size();
+    d.recv = h.recv;
+    d.send = h.send;
+    if (d.nsend > 0) {
+        d.send_idx = upload(*this, h.send_idx.data(), h.send_idx.size());
+        d.sendbuf = static_cast<double *>(dalloc((size_t)d.nsend * 8));
+        if (!d.send_idx || !d.sendbuf) return false;
+    }
+    return true;
+}
+
 int Engine::setup(const sparsh_params &p)
 {
     prm_ = p;
@@ -175,40 +190,91 @@ int Engine::setup(const sparsh_params &p)
         return SPARSH_ENODEV;
     }
     if (p.device >= 0) {
-        if (!check(hipSetDevice(p.device), "hipSetDevice")) return SPARSH_ENODEV;
-        device_ = p.device;
+        if (!check(hipSetDevice(p.device % ndev), "hipSetDevice")) return SPARSH_ENODEV;
+        device_ = p.device % ndev;
     } else {
         (void)hipGetDevice(&device_);
     }
     if (!st_ && !check(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking), "hipStreamCreate")) return SPARSH_ENODEV;
     for (void *q : allocs_) (void)hipFree(q);  // a second setup replaces the resident hierarchy
     allocs_.clear();
+    if (!comm_) comm_ = make_self_comm();
+    const int G = comm_->size, me = comm_->rank;
 
-    if (int rc = setup_host(p); rc != SPARSH_OK) return rc;
+    sparsh_params hp = p;
+    if (G > 1 && me != 0) hp.print_setup = 0;  // one copy of the "Level k:" lines
+    if (int rc = setup_host(hp); rc != SPARSH_OK) return rc;
+    prm_ = p;
 
+    // ---- row partition of every level (multi-GPU).  Levels at or below replicate_rows, and always
+    // the coarsest one (dense direct solve), are held and computed by every rank.
     const int nl = (int)H_.levels.size();
+    parts_.assign((size_t)nl, Partition());
+    repl_level_ = 0;
+    {
+        bool repl = (G == 1);
+        for (int l = 0; l < nl; ++l) {
+            const int n = H_.levels[l].A.nrow;
+            if (!repl && (n <= std::max(p.replicate_rows, 64 * G) || l == nl - 1)) repl = true;
+            if (repl) {
+                parts_[l] = Partition::whole(n, G);
+            } else {
+                parts_[l] = (l == 0) ? make_partition(n, G) : coarse_partition(H_.levels[l - 1].R, parts_[l - 1]);
+                repl_level_ = l + 1;
+            }
+        }
+    }
+    dist_ = (G > 1 && repl_level_ > 0);
+    if (dist_) gather_part_ = make_partition(H_.levels[repl_level_].A.nrow, G);
+
     lev_.assign((size_t)nl, DevLevel());
     int max_blk = 4096;
     for (int l = 0; l < nl; ++l) {
         const HostLevel &h = H_.levels[l];
         DevLevel &d = lev_[l];
-        d.n = h.A.nrow;
-        if (!upload_csr(*this, h.A, d.A, true)) return SPARSH_ENODEV;
+        d.nglob = h.A.nrow;
+        d.replicated = parts_[l].replicated;
         d.fine = (l == 0);  // finest level: separately named kernel instances (profiling)
-        d.diag = upload(*this, h.diag.data(), (size_t)d.n);
-        d.x = static_cast<double *>(dalloc((size_t)d.n * 8));
-        d.x2 = static_cast<double *>(dalloc((size_t)d.n * 8));
-        d.r = static_cast<double *>(dalloc((size_t)d.n * 8));
+        size_t xcap, rcap;
+        if (d.replicated) {
+            d.n = h.A.nrow;
+            if (!upload_csr(*this, h.A, d.A, true)) return SPARSH_ENODEV;
+            d.diag = upload(*this, h.diag.data(), (size_t)d.n);
+            if (l + 1 < nl) {
+                if (!upload_csr(*this, h.P, d.P, false) || !upload_csr(*this, h.R, d.R, false)) return SPARSH_ENODEV;
+                d.P_is_aggregation = h.P_is_aggregation;
+            }
+            xcap = rcap = (size_t)d.n;
+        } else {
+            const Partition &pl = parts_[l];
+            d.n = pl.hi(me) - pl.lo(me);
+            LocalOp la = extract_local(h.A, pl, pl, me);
+            if (!upload_csr(*this, la.M, d.A, true) || !upload_plan(la.plan, d.planA)) return SPARSH_ENODEV;
+            d.diag = upload(*this, h.diag.data() + pl.lo(me), (size_t)d.n);
+            // P_l: my fine rows, columns in the coarse space (replicated coarse space: global columns)
+            LocalOp lp = extract_local(h.P, pl, parts_[l + 1], me);
+            // R_l: my share of the coarse rows; on the boundary to the replicated levels the share is
+            // the balanced gather partition and the result is all-gathered
+            const Partition &rrows = parts_[l + 1].replicated ? gather_part_ : parts_[l + 1];
+            LocalOp lr = extract_local(h.R, rrows, pl, me);
+            if (!upload_csr(*this, lp.M, d.P, false) || !upload_plan(lp.plan, d.planP)) return SPARSH_ENODEV;
+            if (!upload_csr(*this, lr.M, d.R, false) || !upload_plan(lr.plan, d.planR)) return SPARSH_ENODEV;
+            d.P_is_aggregation = h.P_is_aggregation;
+            int xh = d.planA.nhalo;
+            if (l > 0 && !lev_[l - 1].replicated) xh = std::max(xh, lev_[l - 1].planP.nhalo);  // x_l is also P_{l-1}'s input
+            xcap = (size_t)d.n + xh;
+            rcap = (size_t)d.n + d.planR.nhalo;
+        }
+        d.x = static_cast<double *>(dalloc(xcap * 8));
+        d.x2 = static_cast<double *>(dalloc(xcap * 8));
+        d.r = static_cast<double *>(dalloc(rcap * 8));
         if (l > 0) d.b = static_cast<double *>(dalloc((size_t)d.n * 8));
         if (!d.diag || !d.x || !d.x2 || !d.r || (l > 0 && !d.b)) return SPARSH_ENODEV;
-        if (l + 1 < nl) {
-            if (!upload_csr(*this, h.P, d.P, false) || !upload_csr(*this, h.R, d.R, false)) return SPARSH_ENODEV;
-            d.P_is_aggregation = h.P_is_aggregation;
-            max_blk = std::max(max_blk, std::max(partial_count(d.P), partial_count(d.R)));
-        }
+        if (l + 1 < nl) max_blk = std::max(max_blk, std::max(partial_count(d.P), partial_count(d.R)));
         max_blk = std::max(max_blk, partial_count(d.A));
-        (void)hipMemsetAsync(d.x, 0, (size_t)d.n * 8, st_);
-        (void)hipMemsetAsync(d.x2, 0, (size_t)d.n * 8, st_);
+        (void)hipMemsetAsync(d.x, 0, xcap * 8, st_);
+        (void)hipMemsetAsync(d.x2, 0, xcap * 8, st_);
+        (void)hipMemsetAsync(d.r, 0, rcap * 8, st_);
     }
     nL_ = H_.nL;
     coarse_inv_ = upload(*this, H_.coarse_inverse.data(), (size_t)nL_ * nL_);
@@ -223,15 +289,22 @@ int Engine::setup(const sparsh_params &p)
     hist_cap_dev_ = std::min(hist_cap_dev_, 1 << 22);
     hist_dev_ = static_cast<double *>(dalloc((size_t)hist_cap_dev_ * 8));
     if (!part0_ || !part1_ || !scal_ || !hist_dev_) return SPARSH_ENODEV;
+    (void)hipMemsetAsync(scal_, 0, S_COUNT * 8, st_);
     if (!pinned_ && !check(hipHostMalloc(reinterpret_cast<void **>(&pinned_), 64 * sizeof(double), hipHostMallocDefault), "hipHostMalloc"))
         return SPARSH_ENODEV;
     work_.clear();
+    const size_t wcap = (size_t)lev_[0].n + lev_[0].planA.nhalo;  // Krylov vectors may be SpMV inputs: room for the halo
     for (int k = 0; k < 8; ++k) {
-        double *w = static_cast<double *>(dalloc((size_t)A0_.nrow * 8));
+        double *w = static_cast<double *>(dalloc(wcap * 8));
         if (!w) return SPARSH_ENODEV;
+        (void)hipMemsetAsync(w, 0, wcap * 8, st_);
         work_.push_back(w);
     }
     if (!check(hipStreamSynchronize(st_), "setup sync")) return SPARSH_ENODEV;
+    if (!comm_->barrier(st_)) {
+        error = "comm barrier after setup failed: " + comm_->error;
+        return SPARSH_ECOMM;
+    }
     ready_ = true;
     return SPARSH_OK;
 }
@@ -250,10 +323,39 @@ double Engine::read_hist(int it)
     return pinned_[0];
 }
 
+// Halo exchange of one operator's input vector: pack what the peers need, then the transport
+// fills vec[nloc .. nloc+nhalo).  One GPU: nothing to do.
+bool Engine::halo(const DevPlan &p, double *vec)
+{
+    if (!dist_) return true;
+    if (p.nsend > 0) launch_pack(p.nsend, p.send_idx, vec, p.sendbuf, st_);
+    if (!comm_->exchange(p, vec, st_)) {
+        error = "halo exchange failed: " + comm_->error;
+        return false;
+    }
+    return true;
+}
+
+// Reduce per-workgroup partials and update the device scalars; across ranks the local sums are
+// all-reduced in between (one 16-byte ncclAllReduce).
+void Engine::finalize(Fin code, const double *p0, const double *p1, int nblk, int slot, double *hist, int it)
+{
+    if (!dist_) {
+        launch_finalize(code, p0, p1, nblk, scal_, slot, hist, it, st_, 0);
+        return;
+    }
+    launch_finalize(code, p0, p1, nblk, scal_, slot, hist, it, st_, 1);
+    if (!comm_->allreduce_sum(scal_ + S_SUM0, 2, st_)) error = "allreduce failed: " + comm_->error;
+    launch_finalize(code, p0, p1, nblk, scal_, slot, hist, it, st_, 2);
+}
+
 // ---------------------------------------------------------------------------- operators
+// Inputs of SpMV-type operators must have room for the operator's halo behind their own entries
+// (all engine-owned vectors do); on one GPU the plans are empty.
 
 void Engine::op_spmv(int l, const double *x, double *y)
 {
+    halo(lev_[l].planA, const_cast<double *>(x));
     CsrArgs a;
     a.x = x;
     a.y = y;
@@ -262,6 +364,7 @@ void Engine::op_spmv(int l, const double *x, double *y)
 
 void Engine::op_residual(int l, const double *b, const double *x, double *r)
 {
+    halo(lev_[l].planA, const_cast<double *>(x));
     CsrArgs a;
     a.x = x;
     a.b = b;
@@ -271,26 +374,32 @@ void Engine::op_residual(int l, const double *b, const double *x, double *r)
 
 double Engine::op_resnorm(int l, const double *b, const double *x)
 {
+    halo(lev_[l].planA, const_cast<double *>(x));
     CsrArgs a;
     a.x = x;
     a.b = b;
     a.partial = part0_;
     const int np = launch_csr(lev_[l].A, OP_RESNORM, a, lev_[l].fine, st_);
-    launch_finalize(FIN_SQRT, part0_, nullptr, np, scal_, S_RES, nullptr, 0, st_);
+    finalize(FIN_SQRT, part0_, nullptr, np, S_RES, nullptr, 0);
     return read_scalar(S_RES);
 }
 
 void Engine::op_restrict(int l, const double *r, double *bc)
 {
+    DevLevel &L = lev_[l];
+    halo(L.planR, const_cast<double *>(r));
     CsrArgs a;
     a.x = r;
-    a.y = bc;
-    launch_csr(lev_[l].R, OP_SPMV, a, false, st_);
+    const bool gather = dist_ && !L.replicated && lev_[l + 1].replicated;
+    a.y = gather ? bc + gather_part_.lo(comm_->rank) : bc;  // my share of the replicated level's rhs
+    launch_csr(L.R, OP_SPMV, a, false, st_);
+    if (gather && !comm_->allgather(bc, gather_part_, st_)) error = "allgather failed: " + comm_->error;
 }
 
 void Engine::op_prolong(int l, const double *xc, double *xf)
 {
     DevLevel &L = lev_[l];
+    halo(L.planP, const_cast<double *>(xc));
     if (L.P_is_aggregation) {
         launch_prolong_agg(L.n, L.P.col, xc, xf, st_);
     } else {
@@ -307,7 +416,7 @@ double Engine::op_dot(int n, const double *x, const double *y)
 {
     int nb = 0;
     launch_dot(n, x, y, part0_, &nb, st_);
-    launch_finalize(FIN_STORE, part0_, nullptr, nb, scal_, S_TMP, nullptr, 0, st_);
+    finalize(FIN_STORE, part0_, nullptr, nb, S_TMP, nullptr, 0);
     return read_scalar(S_TMP);
 }
 
@@ -324,6 +433,7 @@ void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, doubl
     const bool timed = prof.enabled && &L == &lev_[0];
     for (; k < sweeps; ++k) {
         const bool last = (k == sweeps - 1);
+        halo(L.planA, L.x);
         CsrArgs a;
         a.x = L.x;
         a.b = b;
@@ -435,14 +545,19 @@ int Engine::pcg_init(const double *b, double *x, bool precond)
     ks_.precond = precond;
     ks_.b = b;
     ks_.x = x;
-    op_residual(0, b, x, r);  // r0 = b - A x
+    const double *xin = x;
+    if (dist_) {  // the caller's x has no room for the halo: stage it in an engine vector
+        launch_copy(n, x, work_[3], st_);
+        xin = work_[3];
+    }
+    op_residual(0, b, xin, r);  // r0 = b - A x
     launch_dot(n, r, r, part0_, &nb, st_);
-    if (!precond) launch_finalize(FIN_STORE, part0_, nullptr, nb, scal_, S_RR, nullptr, 0, st_);
-    launch_finalize(FIN_SQRT, part0_, nullptr, nb, scal_, S_RES, nullptr, 0, st_);
+    if (!precond) finalize(FIN_STORE, part0_, nullptr, nb, S_RR, nullptr, 0);
+    finalize(FIN_SQRT, part0_, nullptr, nb, S_RES, nullptr, 0);
     ks_.r1 = read_scalar(S_RES);
     if (precond) {
         vcycle(r, true, part0_, &nb);  // z0 = V(r0), zero initial guess
-        launch_finalize(FIN_STORE, part0_, nullptr, nb, scal_, S_RZ, nullptr, 0, st_);
+        finalize(FIN_STORE, part0_, nullptr, nb, S_RZ, nullptr, 0);
         launch_copy(n, lev_[0].x, p, st_);
     } else {
         launch_copy(n, r, p, st_);
@@ -465,7 +580,7 @@ int Engine::pcg_steps(int nsteps, int *done)
     int rc = SPARSH_OK;
     int did = 0;
     const int check_every = std::max(1, prm_.check_every);
-    while (ks_.count < n && ks_.r1 > prm_.tol && did < nsteps) {
+    while (ks_.count < lev_[0].nglob && ks_.r1 > prm_.tol && did < nsteps) {
         const int count = ++ks_.count;
         ++did;
         CsrArgs a;
@@ -473,16 +588,16 @@ int Engine::pcg_steps(int nsteps, int *done)
         a.y = Ap;
         a.partial = part0_;
         const int np = launch_csr(lev_[0].A, OP_SPMV_DOT, a, lev_[0].fine, st_);  // Ap = A p ; p.Ap
-        launch_finalize(precond ? FIN_PCG_ALPHA : FIN_CG_ALPHA, part0_, nullptr, np, scal_, 0, nullptr, 0, st_);
+        finalize(precond ? FIN_PCG_ALPHA : FIN_CG_ALPHA, part0_, nullptr, np, 0, nullptr, 0);
         launch_cg_update(n, scal_, p, Ap, x, r, part0_, &nb, st_);  // x += alpha p ; r -= alpha Ap ; r.r
         const int slot = std::min(count - 1, hist_cap_dev_ - 1);
         if (precond) {
-            launch_finalize(FIN_SQRT, part0_, nullptr, nb, scal_, S_RES, hist_dev_, slot, st_);
+            finalize(FIN_SQRT, part0_, nullptr, nb, S_RES, hist_dev_, slot);
             vcycle(r, true, part0_, &nb);  // z0 = 0 ; z0 = V(r0) ; fused z0.r0
-            launch_finalize(FIN_PCG_BETA, part0_, nullptr, nb, scal_, 0, nullptr, 0, st_);
+            finalize(FIN_PCG_BETA, part0_, nullptr, nb, 0, nullptr, 0);
             launch_p_update(n, scal_, lev_[0].x, p, st_);  // p = z0 + beta p
         } else {
-            launch_finalize(FIN_CG_BETA, part0_, nullptr, nb, scal_, 0, hist_dev_, slot, st_);
+            finalize(FIN_CG_BETA, part0_, nullptr, nb, 0, hist_dev_, slot);
             launch_p_update(n, scal_, r, p, st_);
         }
         if (count % check_every == 0 || did >= nsteps) {
@@ -512,7 +627,7 @@ int Engine::pcg(const double *b, double *x, int max_iters, double *hist, int his
     if (rc != SPARSH_OK) return rc;
     int did = 0;
     rc = pcg_steps(max_iters, &did);
-    if (rc == SPARSH_OK && ks_.r1 > prm_.tol && ks_.count < lev_[0].n) rc = SPARSH_ENOCONV;
+    if (rc == SPARSH_OK && ks_.r1 > prm_.tol && ks_.count < lev_[0].nglob) rc = SPARSH_ENOCONV;
     const int count = krylov_hist(hist, hist_cap);
     if (iters) *iters = count;
     ks_.active = false;
@@ -525,11 +640,16 @@ int Engine::bicg(const double *b, double *x, int max_iters, double *hist, int hi
     const int n = lev_[0].n;
     double *r0 = work_[0], *r = work_[1], *p = work_[2], *Ap = work_[3], *s = work_[4], *As = work_[5], *p1buf = work_[6];
     int nb = 0;
-    op_residual(0, b, x, r0);
+    const double *xin = x;
+    if (dist_) {
+        launch_copy(n, x, work_[7], st_);
+        xin = work_[7];
+    }
+    op_residual(0, b, xin, r0);
     launch_copy(n, r0, r, st_);
     launch_copy(n, r0, p, st_);
     launch_dot(n, r0, r0, part0_, &nb, st_);
-    launch_finalize(FIN_SQRT, part0_, nullptr, nb, scal_, S_RES, nullptr, 0, st_);
+    finalize(FIN_SQRT, part0_, nullptr, nb, S_RES, nullptr, 0);
     double res = read_scalar(S_RES);
     int count = 0;
     int rc = SPARSH_OK;
@@ -547,7 +667,7 @@ int Engine::bicg(const double *b, double *x, int max_iters, double *hist, int hi
         }
         op_spmv(0, p1, Ap);
         launch_dot2(n, r, r0, Ap, r0, part0_, part1_, &nb, st_);  // alpha1 = r.r0 ; Ap.r0
-        launch_finalize(FIN_BICG_ALPHA, part0_, part1_, nb, scal_, 0, nullptr, 0, st_);
+        finalize(FIN_BICG_ALPHA, part0_, part1_, nb, 0, nullptr, 0);
         launch_bicg_s(n, scal_, r, Ap, s, st_);
         const double *s1 = s;
         if (precond) {
@@ -556,10 +676,10 @@ int Engine::bicg(const double *b, double *x, int max_iters, double *hist, int hi
         }
         op_spmv(0, s1, As);
         launch_dot2(n, As, s, As, As, part0_, part1_, &nb, st_);
-        launch_finalize(FIN_BICG_OMEGA, part0_, part1_, nb, scal_, 0, nullptr, 0, st_);
+        finalize(FIN_BICG_OMEGA, part0_, part1_, nb, 0, nullptr, 0);
         launch_bicg_xr(n, scal_, p1, s1, s, As, r0, x, r, part0_, part1_, &nb, st_);
         const int slot = std::min(count, hist_cap_dev_ - 1);
-        launch_finalize(FIN_BICG_BETA, part0_, part1_, nb, scal_, 0, hist_dev_, slot, st_);
+        finalize(FIN_BICG_BETA, part0_, part1_, nb, 0, hist_dev_, slot);
         launch_bicg_p(n, scal_, r, Ap, p, st_);
         ++count;
         if (count % check_every == 0 || count >= max_iters) {

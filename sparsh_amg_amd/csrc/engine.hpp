@@ -4,17 +4,23 @@
 // (src/AMG_phases.cpp:151-230, src/AMG_main_solvers.cpp:47-458).
 #pragma once
 
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "../../include/sparsh_amg.h"
+#include "comm.hpp"
+#include "dist.hpp"
 #include "host_setup.hpp"
 #include "kernels.hpp"
 
 namespace sparsh {
 
 struct DevLevel {
-    int n = 0;
+    int n = 0;       // rows this rank holds (all of them on a replicated level)
+    int nglob = 0;   // rows of the level
+    bool replicated = true;  // every rank holds and computes the whole level
+    DevPlan planA, planP, planR;  // halo plans of A_l x, P_l x_{l+1}, R_l r_l (empty on one GPU)
     DevCsr A, P, R;
     bool P_is_aggregation = false;
     double *diag = nullptr;
@@ -54,6 +60,12 @@ public:
     hipStream_t stream() const { return st_; }
     const DevLevel &level(int l) const { return lev_[l]; }
     int n0() const { return A0_.nrow; }
+    int local_n0() const { return lev_.empty() ? A0_.nrow : lev_[0].n; }
+    // multi-GPU: install the transport before setup(); the engine owns it
+    void set_comm(std::unique_ptr<Comm> c) { comm_ = std::move(c); }
+    Comm *comm() const { return comm_.get(); }
+    bool distributed() const { return dist_; }
+    const Partition &partition(int l) const { return parts_[l]; }
     void set_stopping(double tol, int max_iter, int check_every)
     {
         prm_.tol = tol;
@@ -99,12 +111,20 @@ private:
     // dot_partial: when non-null the last post-sweep also leaves partial sums of x.b there.
     void vcycle(const double *b0, bool x0_zero, double *dot_partial, int *dot_nblk);
     void smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, double *dot_partial, int *dot_nblk);
+    bool halo(const DevPlan &p, double *vec);  // pack + exchange (no-op on one GPU)
+    void finalize(Fin code, const double *p0, const double *p1, int nblk, int slot, double *hist, int it);
+    bool upload_plan(const HaloPlan &h, DevPlan &d);
     double read_scalar(int slot);
     double read_hist(int it);
 
     int pcg(const double *b, double *x, int max_iters, double *hist, int hist_cap, int *iters, bool precond);
     int bicg(const double *b, double *x, int max_iters, double *hist, int hist_cap, int *iters, bool precond);
 
+    std::unique_ptr<Comm> comm_;
+    std::vector<Partition> parts_;  // row partition of every level
+    Partition gather_part_;         // share of the first replicated level each rank restricts, then all-gathers
+    int repl_level_ = 0;            // first replicated level (0: nothing is partitioned)
+    bool dist_ = false;
     KrylovState ks_;
     HostCsr A0_;
     HostHierarchy H_;

@@ -506,6 +506,12 @@ __global__ __launch_bounds__(kBlock) void prolong_agg_kernel(int n, const int *_
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) xf[i] = 1.0 * xc[agg[i]] + xf[i];
 }
 
+__global__ __launch_bounds__(kBlock) void pack_kernel(int n, const int *__restrict__ idx, const double *__restrict__ vec,
+                                                       double *__restrict__ out)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) out[i] = vec[idx[i]];
+}
+
 __global__ __launch_bounds__(kBlock) void fill_kernel(int n, double v, double *__restrict__ x)
 {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) x[i] = v;
@@ -647,29 +653,40 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(int n, const double *__res
 // One workgroup adds the per-workgroup partials in a fixed order and updates the scalar slots.
 constexpr int kFinBlock = 1024;
 
-__global__ __launch_bounds__(kFinBlock) void finalize_kernel(int code, const double *__restrict__ p0, const double *__restrict__ p1,
-                                                              int nblk, double *__restrict__ scal, int slot_a,
-                                                              double *__restrict__ hist, int it)
+__global__ __launch_bounds__(kFinBlock) void finalize_kernel(int code, int mode, const double *__restrict__ p0,
+                                                              const double *__restrict__ p1, int nblk, double *__restrict__ scal,
+                                                              int slot_a, double *__restrict__ hist, int it)
 {
     __shared__ double red0[kFinBlock / 64], red1[kFinBlock / 64];
-    double a0 = 0.0, a1 = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += kFinBlock) {
-        a0 += p0[i];
-        if (p1) a1 += p1[i];
-    }
-    a0 = wave_sum(a0);
-    a1 = wave_sum(a1);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) {
-        red0[w] = a0;
-        red1[w] = a1;
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
     double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < kFinBlock / 64; ++k) {
-        s0 += red0[k];
-        s1 += red1[k];
+    if (mode != 2) {
+        double a0 = 0.0, a1 = 0.0;
+        for (int i = threadIdx.x; i < nblk; i += kFinBlock) {
+            a0 += p0[i];
+            if (p1) a1 += p1[i];
+        }
+        a0 = wave_sum(a0);
+        a1 = wave_sum(a1);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane == 0) {
+            red0[w] = a0;
+            red1[w] = a1;
+        }
+        __syncthreads();
+        if (threadIdx.x != 0) return;
+        for (int k = 0; k < kFinBlock / 64; ++k) {
+            s0 += red0[k];
+            s1 += red1[k];
+        }
+        if (mode == 1) {  // multi-GPU: leave the local sums for the all-reduce
+            scal[S_SUM0] = s0;
+            scal[S_SUM1] = s1;
+            return;
+        }
+    } else {
+        if (threadIdx.x != 0) return;
+        s0 = scal[S_SUM0];
+        s1 = scal[S_SUM1];
     }
     switch (code) {
     case FIN_STORE: scal[slot_a] = s0; break;
@@ -842,9 +859,16 @@ void launch_dot2(int n, const double *a, const double *b, const double *c, const
 }
 
 void launch_finalize(Fin code, const double *partial0, const double *partial1, int nblk, double *scal, int slot_a, double *hist,
-                     int it, hipStream_t st)
+                     int it, hipStream_t st, int mode)
 {
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kFinBlock), 0, st, (int)code, partial0, partial1, nblk, scal, slot_a, hist, it);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(mode == 2 ? 64 : kFinBlock), 0, st, (int)code, mode, partial0, partial1, nblk, scal,
+                       slot_a, hist, it);
+}
+
+void launch_pack(int n, const int *idx, const double *vec, double *sendbuf, hipStream_t st)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(pack_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, st, n, idx, vec, sendbuf);
 }
 
 void launch_cg_update(int n, const double *scal, const double *p, const double *Ap, double *x, double *r, double *partial,

@@ -92,7 +92,7 @@ void launch_dot(int n, const double *x, const double *y, double *partial, int *n
 // device-resident scalar slots used by the Krylov loops
 enum Slot : int {
     S_RZ = 0, S_PAP, S_ALPHA, S_NALPHA, S_BETA, S_RR, S_RES, S_ZR,
-    S_ALPHA1, S_APR0, S_ASS, S_ASAS, S_OMEGA1, S_RR0, S_TMP, S_COUNT
+    S_ALPHA1, S_APR0, S_ASS, S_ASAS, S_OMEGA1, S_RR0, S_TMP, S_SUM0, S_SUM1, S_COUNT
 };
 
 // finalize codes: reduce partial arrays, then one thread updates the scalar slots
@@ -107,8 +107,12 @@ enum Fin : int {
     FIN_BICG_OMEGA = 7,// ass = sum0 (As.s) ; asas = sum1 (As.As) ; omega1 = ass/asas
     FIN_BICG_BETA = 8  // rr0 = sum0 (r.r0) ; rr = sum1 (r.r) ; beta = rr0/alpha1*(alpha/omega1) ; res = sqrt(rr) ; hist
 };
+// mode 0: reduce the partials and apply `code` (single GPU); mode 1: reduce only, local sums to
+// scal[S_SUM0], scal[S_SUM1] (then all-reduced across ranks); mode 2: apply `code` to those sums
 void launch_finalize(Fin code, const double *partial0, const double *partial1, int nblk, double *scal, int slot_a,
-                     double *hist, int it, hipStream_t st);
+                     double *hist, int it, hipStream_t st, int mode = 0);
+// sendbuf[k] = vec[idx[k]] : pack the entries the peers need (halo exchange)
+void launch_pack(int n, const int *idx, const double *vec, double *sendbuf, hipStream_t st);
 
 // Krylov vector updates with device-resident coefficients (no host round trip)
 // PCG/CG: x += alpha p ; r += (-alpha) Ap ; partial += r_i^2

@@ -1,0 +1,113 @@
+"""Row-block partitioned solver on ONE GPU: G virtual ranks (host threads, in-process transport)
+must reproduce the single-rank solve.  Exercises partitioning, halo plans, the replicated coarse
+levels with their all-gather, and the all-reduced scalars; the RCCL transport differs only in how
+bytes move (comm.cpp)."""
+import threading
+
+import numpy as np
+import pytest
+
+import sparsh_amg_amd as sa
+from sparsh_amg_amd import problems
+
+pytestmark = pytest.mark.gpu
+
+QUIET = dict(print_setup=0, print_solve=0)
+
+
+def run_ranks(rp, ci, v, b, G, method, **kw):
+    group = sa.comm_group_create(G)
+    out = [None] * G
+    errs = []
+
+    def work(r):
+        try:
+            A = sa.sp_matrix_mg(rp, ci, v)
+            A.comm_init_group(group, r)
+            A.setup(sa.default_params(**QUIET, **kw))
+            lo, hi, rep = A.local_range(0)
+            x = np.zeros(hi - lo)
+            if method == "vcycle3":
+                h, rc = A.vcycle(b[lo:hi].copy(), x, iterations=3)
+            else:
+                h, rc = A.solve(method, b[lo:hi].copy(), x)
+            out[r] = (lo, hi, rep, x, h, rc, [A.local_range(l) for l in range(A.nlevels)])
+            A.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    alive = [t.is_alive() for t in ts]
+    assert not any(alive), "a virtual rank hung"
+    assert not errs, errs
+    sa.comm_group_destroy(group)
+    return out
+
+
+CASES = {
+    "p3d": (lambda: problems.poisson3d(30), dict(replicate_rows=2000)),
+    "p2d": (lambda: problems.poisson2d(150), dict(replicate_rows=1500)),
+    "ragged": (lambda: problems.random_spd(20000, 9, seed=11), dict(replicate_rows=1500)),
+}
+
+
+@pytest.mark.parametrize("G", [2, 3, 4])
+@pytest.mark.parametrize("name", list(CASES))
+def test_virtual_ranks_match_single_rank(name, G):
+    gen, kw = CASES[name]
+    rp, ci, v = gen()
+    n = len(rp) - 1
+    rng = np.random.default_rng(2)
+    b = rng.standard_normal(n)
+    A1 = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET))
+    for method in ("pcg", "amg", "pbicg", "cg"):
+        x1 = np.zeros(n)
+        h1, rc1 = A1.solve(method, b, x1)
+        res = run_ranks(rp, ci, v, b, G, method, **kw)
+        # the blocks tile level 0 exactly once
+        spans = sorted((r[0], r[1]) for r in res)
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[k][1] == spans[k + 1][0] for k in range(G - 1))
+        assert not res[0][2], "level 0 should be partitioned in this test"
+        nparts = sum(1 for (lo, hi, rep) in res[0][6] if not rep)
+        assert nparts >= 2, "expected at least two partitioned levels"
+        x = np.concatenate([r[3] for r in sorted(res, key=lambda t: t[0])])
+        for r in res:
+            assert r[5] == rc1
+            assert np.array_equal(r[4], res[0][4]), "ranks disagree on the residual history"
+        h = res[0][4]
+        if method == "cg":
+            k = min(20, len(h), len(h1))
+            assert np.allclose(h[:k], h1[:k], rtol=1e-9)
+        else:
+            assert len(h) == len(h1)
+            tol = np.where(h1 >= 1e-6 * h1[0], 1e-8, 1e-4)
+            assert np.all(np.abs(h - h1) <= tol * h1), np.abs(h / h1 - 1).max()
+        assert np.linalg.norm(x - x1) <= 1e-8 * np.linalg.norm(x1)
+
+
+def test_fixed_cycles_bitwise_rows():
+    """With reductions out of the picture (fixed number of V-cycles) the partitioned cycle is
+    the same arithmetic row by row: the solution matches the single-rank one bitwise."""
+    rp, ci, v = problems.poisson3d(30)
+    n = len(rp) - 1
+    b = np.ones(n)
+    A1 = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET))
+    x1 = np.zeros(n)
+    A1.vcycle(b, x1, iterations=3)
+    res = run_ranks(rp, ci, v, b, 3, "vcycle3", replicate_rows=2000)
+    x = np.concatenate([r[3] for r in sorted(res, key=lambda t: t[0])])
+    assert np.array_equal(x, x1)
+
+
+def test_everything_replicated_small_problem():
+    rp, ci, v = problems.poisson2d(60)
+    n = len(rp) - 1
+    b = np.ones(n)
+    res = run_ranks(rp, ci, v, b, 2, "pcg")  # default replicate_rows > n: every rank solves it all
+    assert all(r[2] for r in res) and all(r[1] - r[0] == n for r in res)
+    assert np.array_equal(res[0][3], res[1][3])
