@@ -583,6 +583,7 @@ int Engine::pcg_steps(int nsteps, int *done)
     while (ks_.count < lev_[0].nglob && ks_.r1 > prm_.tol && did < nsteps) {
         const int count = ++ks_.count;
         ++did;
+        halo(lev_[0].planA, p);
         CsrArgs a;
         a.x = p;
         a.y = Ap;
