@@ -526,10 +526,11 @@ int sparsh_bench_op(sparsh_handle h, int op, int level, int reps, double *avg_se
             launch_dot((int)n, x.p, b.p, E.level(0).r, &nb, st);
         } break;
         case 7: launch_axpby((int)n, 0.5, x.p, 0.5, y.p, st); break;
+        case 8: launch_copy_int((int)n, L.A.rowptr, reinterpret_cast<int *>(y.p), st); break;  // n int32: reads 4n, writes 4n
         default: break;
         }
     };
-    if (op < 0 || op > 7) return fail(SPARSH_EINVAL, "unknown op");
+    if (op < 0 || op > 8) return fail(SPARSH_EINVAL, "unknown op");
     for (int i = 0; i < 3; ++i) run();
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);

@@ -512,6 +512,12 @@ __global__ __launch_bounds__(kBlock) void pack_kernel(int n, const int *__restri
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) out[i] = vec[idx[i]];
 }
 
+// 4-byte-per-lane streaming copy: calibrates rocprof's FETCH_SIZE for int32 index streams
+__global__ __launch_bounds__(kBlock) void copy_int_kernel(int n, const int *__restrict__ x, int *__restrict__ y)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) y[i] = x[i];
+}
+
 __global__ __launch_bounds__(kBlock) void fill_kernel(int n, double v, double *__restrict__ x)
 {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) x[i] = v;
@@ -829,6 +835,12 @@ void launch_fill(int n, double v, double *x, hipStream_t st)
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, st, n, v, x);
+}
+
+void launch_copy_int(int n, const int *x, int *y, hipStream_t st)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(copy_int_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, st, n, x, y);
 }
 
 void launch_copy(int n, const double *x, double *y, hipStream_t st)

@@ -84,6 +84,7 @@ void launch_gemv(int n, const double *M, const double *b, double *x, hipStream_t
 // ---- BLAS-1 (daxpby/daxpbyc kernels, cublasDaxpy/Ddot/Dnrm2, thrust::fill of the reference)
 void launch_fill(int n, double v, double *x, hipStream_t st);
 void launch_copy(int n, const double *x, double *y, hipStream_t st);
+void launch_copy_int(int n, const int *x, int *y, hipStream_t st);  // PMC calibration of 4-byte streams
 // y = a*x + b*y with host scalars
 void launch_axpby(int n, double a, const double *x, double b, double *y, hipStream_t st);
 // partial sums of x.y (nblocks returned through *nblk)

@@ -1,0 +1,163 @@
+"""BASELINE.json configurations on the GPU: the C++ drop-in entry points end to end, the 2D / 3D /
+unstructured configs against the oracle at sizes the oracle finishes in seconds, and the full-size
+10 M-row config through size-independent properties."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+import sparsh_amg_amd as sa
+from sparsh_amg_amd import problems
+from conftest import ROOT, hist_tolerance
+
+pytestmark = pytest.mark.gpu
+QUIET = dict(print_setup=0, print_solve=0)
+LIB_DIR = os.path.join(ROOT, "sparsh_amg_amd")
+
+
+def _hist_ok(h, ho):
+    assert len(h) == len(ho), (len(h), len(ho))
+    err = np.abs(h - ho) / ho
+    assert np.all(err <= hist_tolerance(ho)), f"max rel err {err.max():.3e} at {err.argmax()}"
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    d = tmp_path_factory.mktemp("drv")
+    exe = d / "dropin_driver"
+    cmd = ["g++", "-std=c++17", "-O1", f"-I{os.path.join(ROOT, 'include')}", os.path.join(ROOT, "tests", "cpp", "dropin_driver.cpp"),
+           "-o", str(exe), f"-L{LIB_DIR}", "-lsparsh_amg", f"-Wl,-rpath,{LIB_DIR}", "-L/opt/rocm/lib", "-L/opt/rocm/lib/llvm/lib",
+           "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib/llvm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rp, ci, v = problems.poisson2d(120)
+    b = np.ones(len(rp) - 1)
+    mf, rf = str(d / "m.txt"), str(d / "r.txt")
+    problems.write_coo(mf, rf, rp, ci, v, b)
+    return str(exe), mf, rf, (rp, ci, v, b)
+
+
+@pytest.mark.parametrize("entry,method", [("mi", "amg"), ("ci", "amg"), ("cpu", "amg"), ("pcg1", "pcg"), ("pcg4", "pcg"),
+                                          ("pbicg1", "pbicg"), ("pbicg4", "pbicg"), ("cg2", "cg"), ("bicg1", "bicg")])
+def test_cpp_entry_points_on_device(driver, entry, method):
+    exe, mf, rf, (rp, ci, v, b) = driver
+    r = subprocess.run([exe, mf, rf, entry], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = re.search(r"RESULT (\S+) residual (\S+) x0 (\S+)", r.stdout)
+    assert m, r.stdout[-2000:]
+    assert float(m.group(2)) <= 1.001e-8
+    xo, ho = oracle.solve(method, oracle.Csr(rp, ci, v), b)
+    assert abs(float(m.group(3)) - xo[0]) <= 1e-9 * abs(xo[0])
+    out = r.stdout
+    if method == "amg":
+        # reference's stdout format: "Level k:\t<n>" lines and "<cycle> <residual>" lines
+        assert re.search(r"^Level 0:\t14400$", out, re.M) and re.search(r"^1 \d", out, re.M)
+        assert len(re.findall(r"^\d+ [0-9.e+-]+$", out, re.M)) == len(ho)
+    elif method in ("pcg", "cg"):
+        assert len(re.findall(r"^\d+\t[0-9.e+-]+$", out, re.M)) == len(ho)
+
+
+def test_sor_entry_point_is_a_stub(driver):
+    exe, mf, rf, _ = driver
+    r = subprocess.run([exe, mf, rf, "sor"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "not part of the MI355X build" in r.stderr
+
+
+def test_config1_2d_poisson_pcg_vs_oracle():
+    """configs[1]: 5-pt 2D Poisson (here 500^2 = 250k rows so the oracle takes seconds)."""
+    rp, ci, v = problems.poisson2d(500)
+    n = len(rp) - 1
+    b = np.ones(n)
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET))
+    x = np.zeros(n)
+    h, rc = A.solve("pcg", b, x)
+    xo, ho = oracle.solve("pcg", oracle.Csr(rp, ci, v), b, prm=oracle.params(threads=sa.host_cpus()))
+    assert rc == 0
+    _hist_ok(h, ho)
+    assert np.linalg.norm(x - xo) <= 1e-8 * np.linalg.norm(xo)
+
+
+def test_config4_unstructured_pbicgstab_vs_oracle():
+    """configs[4]: irregular-nnz SPD matrix (P1-FEM M + dt K on a Delaunay mesh, the offline stand-in
+    for SuiteSparse parabolic_fem), AMG-BiCGStab."""
+    rp, ci, v = problems.fem_unstructured(60000, seed=7)
+    n = len(rp) - 1
+    lens = np.diff(rp)
+    assert lens.min() <= 4 and lens.max() >= 10  # genuinely ragged
+    rng = np.random.default_rng(4)
+    b = rng.standard_normal(n) * 1e-3
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET))
+    O = oracle.Csr(rp, ci, v)
+    S = O.to_scipy()
+    x = np.zeros(n)
+    h, rc = A.solve("pbicg", b, x)
+    xo, ho = oracle.solve("pbicg", O, b)
+    assert rc == 0
+    # BiCGStab on this matrix creeps from 1e-7 to 1e-8 non-monotonically; that tail amplifies
+    # rounding differences (the reference's own un-preconditioned BiCGStab shows the same,
+    # SURVEY Appendix A.1), so: strict on the head, loose on length, strict on the answer.
+    # (measured: the device/oracle gap starts at 1e-14 relative and grows ~10x per iteration)
+    k = min(8, len(h), len(ho))
+    assert np.all(np.abs(h[:k] - ho[:k]) <= 1e-6 * ho[:k])
+    assert abs(len(h) - len(ho)) <= max(3, len(ho) // 3)
+    assert np.linalg.norm(b - S @ x) <= 1.001e-8
+    assert np.linalg.norm(x - xo) <= 1e-5 * np.linalg.norm(xo)
+    # the SPD solver on the same matrix is held to the strict history tolerance
+    x = np.zeros(n)
+    h, rc = A.solve("pcg", b, x)
+    xo, ho = oracle.solve("pcg", O, b)
+    assert rc == 0
+    _hist_ok(h, ho)
+    assert np.linalg.norm(x - xo) <= 1e-8 * np.linalg.norm(xo)
+    # SpMV stress on the ragged rows, every level, bitwise
+    H = oracle.Hierarchy(O)
+    for l in range(A.nlevels):
+        xx = rng.standard_normal(A.level_info(l)["nrow"])
+        assert np.array_equal(A.op_spmv(l, xx), oracle.spmv(H.A(l), xx))
+
+
+def test_config2_full_size_properties():
+    """configs[2] at full size (216^3 = 10 077 696 rows): properties that need no oracle run."""
+    import scipy.sparse as sp
+
+    rp, ci, v = problems.poisson3d(216)
+    n = len(rp) - 1
+    assert n == 10077696 and rp[-1] == 70263936
+    S = sp.csr_matrix((v, ci, rp), shape=(n, n))
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET))
+    levels = [A.level_info(l)["nrow"] for l in range(A.nlevels)]
+    assert levels[:6] == [10077696, 5038848, 2519424, 1259712, 629856, 314928] and levels[-1] <= 4000
+    b = np.ones(n)
+    x = np.zeros(n)
+    h, rc = A.solve("pcg", b, x)
+    assert rc == 0 and h[-1] <= 1e-8 and np.all(np.diff(np.log(h)) < 0.5)
+    # independent residual on the host
+    # CG tracks the residual by recurrence (as the reference does); at a 1e-12 reduction it may
+    # differ from the true residual by O(eps * ||A|| * ||x||)
+    true_r = np.linalg.norm(b - S @ x)
+    assert abs(true_r - h[-1]) <= 100 * np.finfo(float).eps * 12.0 * np.linalg.norm(x)
+    assert true_r <= 5e-8
+    # SpMV bitwise against a scalar-order host product on a sample of rows
+    rng = np.random.default_rng(0)
+    xx = rng.standard_normal(n)
+    y = A.op_spmv(0, xx)
+    rows = rng.integers(0, n, size=2000)
+    for i in rows:
+        s = 0.0
+        for j in range(rp[i], rp[i + 1]):
+            s += v[j] * xx[ci[j]]
+        assert y[i] == s
+    # the V(7,7) cycle from a zero guess is linear and symmetric (SPD preconditioner)
+    b1 = rng.standard_normal(n)
+    b2 = rng.standard_normal(n)
+    z1 = np.zeros(n)
+    A.vcycle(b1, z1, iterations=1)
+    z2 = np.zeros(n)
+    A.vcycle(b2, z2, iterations=1)
+    z12 = np.zeros(n)
+    A.vcycle(2.0 * b1 - 0.5 * b2, z12, iterations=1)
+    assert np.linalg.norm(z12 - (2.0 * z1 - 0.5 * z2)) <= 1e-12 * np.linalg.norm(z12)
+    assert abs(z1 @ b2 - z2 @ b1) <= 1e-10 * abs(z1 @ b2)

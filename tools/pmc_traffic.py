@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""HBM traffic of the dominant kernel from rocprofv3 PMC counters (run ON the GPU box).
+
+Usage (two separate counter passes, as MI355X_MICROARCH.md prescribes; no trace domains mixed in):
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d OUT/fetch -- python3 tools/pmc_traffic.py --run
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d OUT/write -- python3 tools/pmc_traffic.py --run
+  python3 tools/pmc_traffic.py --summarize OUT/fetch OUT/write --out profiles/pmc_latest.json
+
+--run launches, on the 216^3 hierarchy with the default kernel policy, the finest-level fused Jacobi
+sweep plus three calibration kernels of known byte counts: fp64 axpby (8-B/lane loads), fp64 dot,
+int32 copy (4-B/lane loads).  --summarize converts counter values (KiB) to bytes, derives the
+FETCH_SIZE correction factor of each access width from the calibration kernels (the gfx950 note:
+wide coalesced reads are tallied at half their size) and applies them to the Jacobi kernel's streams.
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+N_GRID = 216
+
+
+def run():
+    import sparsh_amg_amd as sa
+    from sparsh_amg_amd import problems
+
+    rp, ci, v = problems.poisson3d(N_GRID)
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, print_solve=0))
+    for op in ("axpby", "dot", "copy_int", "jacobi"):
+        A.bench_op(op, 0, 4)
+
+
+def collect(d):
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    out = {}
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"]
+        key = None
+        if "axpby_kernel" in name:
+            key = "axpby"
+        elif "dot_kernel" in name and "dot2" not in name:
+            key = "dot"
+        elif "copy_int_kernel" in name:
+            key = "copy_int"
+        elif ("sell_kernel<2" in name or "csr_block_kernel<2" in name) and ", 1>" in name:
+            key = "jacobi"
+        if key:
+            out.setdefault(key, []).append(float(r["Counter_Value"]) * 1024.0)
+    return {k: sum(v) / len(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
+
+
+def summarize(fetch_dir, write_dir, out_path):
+    n = N_GRID ** 3
+    nnz = 7 * n - 6 * N_GRID ** 2
+    fetch, cnt = collect(fetch_dir)
+    write, _ = collect(write_dir)
+    known_read = {"axpby": 16 * n, "dot": 16 * n, "copy_int": 4 * n}
+    known_write = {"axpby": 8 * n, "dot": 0, "copy_int": 4 * n}
+    f8 = known_read["axpby"] / fetch["axpby"]      # 8-byte-per-lane loads
+    f8b = known_read["dot"] / fetch["dot"]
+    f4 = known_read["copy_int"] / fetch["copy_int"]  # 4-byte-per-lane loads
+    wf8 = known_write["axpby"] / write["axpby"]
+    wf4 = known_write["copy_int"] / write["copy_int"]
+    # Jacobi kernel streams: 4-byte loads = column indices (padded ELL) + 2 rowptr reads (one line);
+    # 8-byte loads = values, b, d, x_i, gathered x.  raw = bytes4/f4 + bytes8/f8  ->  solve for bytes8.
+    pad_nnz = 7 * n
+    bytes4 = 4 * pad_nnz + 4 * n
+    bytes8 = (fetch["jacobi"] - bytes4 / f4) * f8
+    read_total = bytes4 + bytes8
+    alg = 12 * nnz + 36 * n
+    res = {
+        "_how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); counter KiB -> bytes; per-width correction from "
+                "calibration kernels of known size run in the same process (tools/pmc_traffic.py)",
+        "raw_fetch_bytes": fetch, "raw_write_bytes": write, "dispatches": cnt,
+        "fetch_correction": {"8B_per_lane(axpby)": f8, "8B_per_lane(dot)": f8b, "4B_per_lane(copy_int)": f4},
+        "write_correction": {"8B_per_lane": wf8, "4B_per_lane": wf4},
+        "jacobi_fine_read_bytes": read_total,
+        "jacobi_fine_write_bytes": write["jacobi"] * wf8,
+        "jacobi_fine_bytes_per_launch": read_total + write["jacobi"] * wf8,
+        "jacobi_fine_algorithmic_bytes": alg,
+        "ratio_traffic_over_algorithmic": (read_total + write["jacobi"] * wf8) / alg,
+        "x_vector_fetches_per_entry": (bytes8 - 8 * pad_nnz - 16 * n) / (8 * n),
+    }
+    with open(out_path, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--run", action="store_true")
+    ap.add_argument("--summarize", nargs=2)
+    ap.add_argument("--out", default="profiles/pmc_latest.json")
+    a = ap.parse_args()
+    if a.run:
+        run()
+    elif a.summarize:
+        summarize(a.summarize[0], a.summarize[1], a.out)
