@@ -56,6 +56,7 @@ Engine::Engine(int nrow, int ncol, const int *rowptr, const int *col, const doub
 Engine::~Engine()
 {
     if (st_) (void)hipStreamSynchronize(st_);
+    drop_graph();
     for (auto e : prof.ev) (void)hipEventDestroy(e);
     for (void *p : allocs_) (void)hipFree(p);
     if (pinned_) (void)hipHostFree(pinned_);
@@ -288,8 +289,11 @@ int Engine::setup(const sparsh_params &p)
     hist_cap_dev_ = std::max(1024, p.max_iter + 2);
     hist_cap_dev_ = std::min(hist_cap_dev_, 1 << 22);
     hist_dev_ = static_cast<double *>(dalloc((size_t)hist_cap_dev_ * 8));
-    if (!part0_ || !part1_ || !scal_ || !hist_dev_) return SPARSH_ENODEV;
+    iter_ctr_ = static_cast<int *>(dalloc(sizeof(int)));
+    if (!part0_ || !part1_ || !scal_ || !hist_dev_ || !iter_ctr_) return SPARSH_ENODEV;
     (void)hipMemsetAsync(scal_, 0, S_COUNT * 8, st_);
+    (void)hipMemsetAsync(iter_ctr_, 0, sizeof(int), st_);
+    drop_graph();  // a captured iteration refers to the buffers of the previous setup
     if (!pinned_ && !check(hipHostMalloc(reinterpret_cast<void **>(&pinned_), 64 * sizeof(double), hipHostMallocDefault), "hipHostMalloc"))
         return SPARSH_ENODEV;
     work_.clear();
@@ -341,12 +345,12 @@ bool Engine::halo(const DevPlan &p, double *vec)
 void Engine::finalize(Fin code, const double *p0, const double *p1, int nblk, int slot, double *hist, int it)
 {
     if (!dist_) {
-        launch_finalize(code, p0, p1, nblk, scal_, slot, hist, it, st_, 0);
+        launch_finalize(code, p0, p1, nblk, scal_, slot, hist, it, st_, 0, iter_ctr_, hist_cap_dev_);
         return;
     }
-    launch_finalize(code, p0, p1, nblk, scal_, slot, hist, it, st_, 1);
+    launch_finalize(code, p0, p1, nblk, scal_, slot, hist, it, st_, 1, iter_ctr_, hist_cap_dev_);
     if (!comm_->allreduce_sum(scal_ + S_SUM0, 2, st_)) error = "allreduce failed: " + comm_->error;
-    launch_finalize(code, p0, p1, nblk, scal_, slot, hist, it, st_, 2);
+    launch_finalize(code, p0, p1, nblk, scal_, slot, hist, it, st_, 2, iter_ctr_, hist_cap_dev_);
 }
 
 // ---------------------------------------------------------------------------- operators
@@ -566,41 +570,86 @@ int Engine::pcg_init(const double *b, double *x, bool precond)
     return SPARSH_OK;
 }
 
+// One pass of the loop body of Solver_PCG_1 / Solver_CG_1 (src/AMG_main_solvers.cpp:138-152,
+// :72-79) as stream work only; slot = residual-history index, or -1 to take it from the device
+// counter (graph replay).
+void Engine::pcg_body(bool precond, int slot)
+{
+    const int n = lev_[0].n;
+    double *r = work_[0], *p = work_[1], *Ap = work_[2];
+    double *x = ks_.x;
+    int nb = 0;
+    halo(lev_[0].planA, p);
+    CsrArgs a;
+    a.x = p;
+    a.y = Ap;
+    a.partial = part0_;
+    const int np = launch_csr(lev_[0].A, OP_SPMV_DOT, a, lev_[0].fine, st_);  // Ap = A p ; p.Ap
+    finalize(precond ? FIN_PCG_ALPHA : FIN_CG_ALPHA, part0_, nullptr, np, 0, nullptr, 0);
+    launch_cg_update(n, scal_, p, Ap, x, r, part0_, &nb, st_);  // x += alpha p ; r -= alpha Ap ; r.r
+    if (precond) {
+        finalize(FIN_SQRT, part0_, nullptr, nb, S_RES, hist_dev_, slot);
+        vcycle(r, true, part0_, &nb);  // z0 = 0 ; z0 = V(r0) ; fused z0.r0
+        finalize(FIN_PCG_BETA, part0_, nullptr, nb, 0, nullptr, 0);
+        launch_p_update(n, scal_, lev_[0].x, p, st_);  // p = z0 + beta p
+    } else {
+        finalize(FIN_CG_BETA, part0_, nullptr, nb, 0, hist_dev_, slot);
+        launch_p_update(n, scal_, r, p, st_);
+    }
+}
+
+void Engine::drop_graph()
+{
+    if (graph_.exec) (void)hipGraphExecDestroy(graph_.exec);
+    if (graph_.graph) (void)hipGraphDestroy(graph_.graph);
+    graph_ = GraphState();
+}
+
+// Capture one PCG iteration (≈230 kernel launches at 13 levels) into a hipGraph.  Every buffer
+// the iteration touches is engine-owned and fixed; the Jacobi ping-pong makes a V-cycle from a
+// zero guess start and end in fixed buffers, so the captured launches stay valid for every
+// later iteration and solve on the same x vector.
+bool Engine::capture_graph(bool precond)
+{
+    drop_graph();
+    if (hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
+    pcg_body(precond, -1);
+    hipGraph_t g = nullptr;
+    if (hipStreamEndCapture(st_, &g) != hipSuccess || !g) return false;
+    hipGraphExec_t e = nullptr;
+    if (hipGraphInstantiate(&e, g, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        return false;
+    }
+    graph_.graph = g;
+    graph_.exec = e;
+    graph_.x = ks_.x;
+    graph_.precond = precond;
+    return true;
+}
+
 int Engine::pcg_steps(int nsteps, int *done)
 {
     if (!ks_.active) {
         error = "krylov_init has not been called";
         return SPARSH_ESTATE;
     }
-    const int n = lev_[0].n;
     const bool precond = ks_.precond;
-    double *r = work_[0], *p = work_[1], *Ap = work_[2];
-    double *x = ks_.x;
-    int nb = 0;
     int rc = SPARSH_OK;
     int did = 0;
     const int check_every = std::max(1, prm_.check_every);
+    // hipGraph replay: single GPU, no per-launch profiling events
+    bool use_graph = prm_.use_graph && !dist_ && !prof.enabled && (int)lev_.size() > 1;
+    if (use_graph && !(graph_.exec && graph_.x == ks_.x && graph_.precond == precond)) use_graph = capture_graph(precond);
+    if (use_graph) (void)hipMemcpyAsync(iter_ctr_, &ks_.count, sizeof(int), hipMemcpyHostToDevice, st_);
     while (ks_.count < lev_[0].nglob && ks_.r1 > prm_.tol && did < nsteps) {
         const int count = ++ks_.count;
         ++did;
-        halo(lev_[0].planA, p);
-        CsrArgs a;
-        a.x = p;
-        a.y = Ap;
-        a.partial = part0_;
-        const int np = launch_csr(lev_[0].A, OP_SPMV_DOT, a, lev_[0].fine, st_);  // Ap = A p ; p.Ap
-        finalize(precond ? FIN_PCG_ALPHA : FIN_CG_ALPHA, part0_, nullptr, np, 0, nullptr, 0);
-        launch_cg_update(n, scal_, p, Ap, x, r, part0_, &nb, st_);  // x += alpha p ; r -= alpha Ap ; r.r
         const int slot = std::min(count - 1, hist_cap_dev_ - 1);
-        if (precond) {
-            finalize(FIN_SQRT, part0_, nullptr, nb, S_RES, hist_dev_, slot);
-            vcycle(r, true, part0_, &nb);  // z0 = 0 ; z0 = V(r0) ; fused z0.r0
-            finalize(FIN_PCG_BETA, part0_, nullptr, nb, 0, nullptr, 0);
-            launch_p_update(n, scal_, lev_[0].x, p, st_);  // p = z0 + beta p
-        } else {
-            finalize(FIN_CG_BETA, part0_, nullptr, nb, 0, hist_dev_, slot);
-            launch_p_update(n, scal_, r, p, st_);
-        }
+        if (use_graph)
+            (void)hipGraphLaunch(graph_.exec, st_);
+        else
+            pcg_body(precond, slot);
         if (count % check_every == 0 || did >= nsteps) {
             ks_.r1 = read_hist(slot);
             if (prm_.print_solve) std::printf("%d\t%g\n", count, ks_.r1);

@@ -38,6 +38,13 @@ struct KrylovState {
     double r1 = 0.0;
 };
 
+struct GraphState {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    double *x = nullptr;  // solution vector the captured iteration updates
+    bool precond = false;
+};
+
 struct ProfileData {
     bool enabled = false;
     std::vector<hipEvent_t> ev;  // pairs
@@ -117,6 +124,9 @@ private:
     double read_scalar(int slot);
     double read_hist(int it);
 
+    void pcg_body(bool precond, int slot);
+    bool capture_graph(bool precond);
+    void drop_graph();
     int pcg(const double *b, double *x, int max_iters, double *hist, int hist_cap, int *iters, bool precond);
     int bicg(const double *b, double *x, int max_iters, double *hist, int hist_cap, int *iters, bool precond);
 
@@ -142,6 +152,8 @@ private:
     double *part0_ = nullptr, *part1_ = nullptr;
     int part_cap_ = 0;
     double *hist_dev_ = nullptr;
+    int *iter_ctr_ = nullptr;     // device-side residual-history index (graph replays)
+    GraphState graph_;
     int hist_cap_dev_ = 0;
     double *pinned_ = nullptr;    // host-pinned staging for scalar read-back
     std::vector<double *> work_;  // level-0 work vectors of the Krylov loops

@@ -661,7 +661,8 @@ constexpr int kFinBlock = 1024;
 
 __global__ __launch_bounds__(kFinBlock) void finalize_kernel(int code, int mode, const double *__restrict__ p0,
                                                               const double *__restrict__ p1, int nblk, double *__restrict__ scal,
-                                                              int slot_a, double *__restrict__ hist, int it)
+                                                              int slot_a, double *__restrict__ hist, int it, int *__restrict__ iter_ctr,
+                                                              int hist_cap)
 {
     __shared__ double red0[kFinBlock / 64], red1[kFinBlock / 64];
     double s0 = 0.0, s1 = 0.0;
@@ -694,12 +695,17 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(int code, int mode,
         s0 = scal[S_SUM0];
         s1 = scal[S_SUM1];
     }
+    // residual-history slot: explicit (eager launches) or a device-side counter (graph replays,
+    // where kernel arguments are frozen)
+    int hslot = it;
+    if (hist && it < 0) hslot = (*iter_ctr)++;
+    if (hslot >= hist_cap) hslot = hist_cap - 1;
     switch (code) {
     case FIN_STORE: scal[slot_a] = s0; break;
     case FIN_SQRT: {
         const double v = sqrt(s0);
         scal[slot_a] = v;
-        if (hist) hist[it] = v;
+        if (hist) hist[hslot] = v;
     } break;
     case FIN_PCG_ALPHA: {
         scal[S_PAP] = s0;
@@ -725,7 +731,7 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(int code, int mode,
         const double res = sqrt(s * beta);
         scal[S_RES] = res;
         scal[S_RR] = s0;
-        if (hist) hist[it] = res;
+        if (hist) hist[hslot] = res;
     } break;
     case FIN_BICG_ALPHA: {
         scal[S_ALPHA1] = s0;
@@ -744,7 +750,7 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(int code, int mode,
         scal[S_RR0] = s0;
         const double res = sqrt(s1);
         scal[S_RES] = res;
-        if (hist) hist[it] = res;
+        if (hist) hist[hslot] = res;
     } break;
     default: break;
     }
@@ -871,10 +877,10 @@ void launch_dot2(int n, const double *a, const double *b, const double *c, const
 }
 
 void launch_finalize(Fin code, const double *partial0, const double *partial1, int nblk, double *scal, int slot_a, double *hist,
-                     int it, hipStream_t st, int mode)
+                     int it, hipStream_t st, int mode, int *iter_ctr, int hist_cap)
 {
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(mode == 2 ? 64 : kFinBlock), 0, st, (int)code, mode, partial0, partial1, nblk, scal,
-                       slot_a, hist, it);
+                       slot_a, hist, it, iter_ctr, hist_cap);
 }
 
 void launch_pack(int n, const int *idx, const double *vec, double *sendbuf, hipStream_t st)

@@ -121,3 +121,18 @@ def write_coo(path_matrix: str, path_rhs: str, rowptr, col, val, b):
         f.write(f"{n}\n")
         for v in b:
             f.write(f"{float(v):.17g}\n")
+
+
+def read_matrix_market(path: str):
+    """A real MatrixMarket reader (1-based indices, `symmetric` expanded, comments skipped) next
+    to the reference's native readers (src/AMG_file_read.cpp:39-185, which accept neither);
+    e.g. SuiteSparse parabolic_fem.mtx when it is available.  Returns sorted CSR arrays."""
+    import scipy.io
+    import scipy.sparse as sp
+
+    A = sp.csr_matrix(scipy.io.mmread(path))
+    A.sum_duplicates()
+    A.sort_indices()
+    if A.nnz >= 2**31:
+        raise ValueError("nnz does not fit int32 indices")
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)

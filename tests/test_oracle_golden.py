@@ -170,6 +170,27 @@ def test_poisson3d_40_beck(p3d, golden):
     assert abs(h[-1] - g["amg"]["last"]) <= 1e-3 * h[-1]
 
 
+@pytest.mark.slow
+def test_poisson3d_100_level1_6(golden):
+    """1 M rows with the reference's own level1 = 6: the coarsest level has 31 250 rows, solved by
+    the oracle's banded LU as PARDISO does in the reference.  Whole PCG history vs Appendix A.2."""
+    import os
+
+    rp, ci, v = problems.poisson3d(100)
+    g = golden["poisson3d_100"]
+    assert len(rp) - 1 == g["nrow"] and rp[-1] == g["nnz"]
+    A = oracle.Csr(rp, ci, v)
+    H = oracle.Hierarchy(A, oracle.params(threads=min(8, os.cpu_count() or 1)))
+    assert [H.A(i).shape[0] for i in range(H.nlevels)] == g["hem"]["levels_nrow"]
+    assert [H.A(i).nnz for i in range(H.nlevels)] == g["hem"]["levels_nnz_stored"]
+    x, h, _ = H.pcg(np.ones(len(rp) - 1))
+    gp = g["hem"]["pcg"]
+    _check_hist(h, gp["hist"])
+    assert abs(h[0] - gp["hist"][0]) <= 1e-12 * gp["hist"][0]
+    assert abs(np.linalg.norm(x) - gp["xnorm"]) <= 1e-10 * gp["xnorm"]
+    assert abs(x[0] - gp["x0"]) <= 1e-10
+
+
 def test_operators_vs_scipy():
     rp, ci, v = problems.random_spd(3000, 9, seed=3)
     A = oracle.Csr(rp, ci, v)
