@@ -183,7 +183,13 @@ def main():
     # dominant kernel: fused Jacobi sweep on the finest level, timed by HIP events on the
     # engine's stream inside the timed region (sparsh_profile)
     pr = A.profile_read()
-    jac_bytes = 12 * pr["nnz"] + 36 * pr["nrow"]  # this rank's block of the finest level
+    jac_bytes = 12 * pr["nnz"] + 36 * pr["nrow"]  # SURVEY §8d CSR model, this rank's block of the finest level
+    fmt, stored = A.level_format(0)
+    fmt_name = {3: "sdia_kernel", 2: "sell_kernel", 1: "csr_wave_kernel", 0: "csr_block_kernel"}[fmt]
+    # bytes the chosen layout really has to move per sweep: values (+ column indices unless the
+    # layout stores diagonals), b, x_i / gathered x once, x_new; the diagonal comes out of the
+    # value stream for the mirrors
+    fmt_bytes = {3: 8 * stored + 24 * pr["nrow"], 2: 12 * stored + 4 * pr["nrow"] + 24 * pr["nrow"]}.get(fmt, jac_bytes)
     roof = None
     if pr["launches"] > 0:
         avg = pr["seconds"] / pr["launches"]
@@ -198,8 +204,12 @@ def main():
         roof = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "kernel": "sell_kernel<OP_JACOBI=2, NT=true, TAG=1> (fused Jacobi sweep, finest level)", "launches": pr["launches"],
+            "kernel": f"{fmt_name}<OP_JACOBI=2, NT=true, TAG=1> (fused Jacobi sweep, finest level)", "launches": pr["launches"],
             "avg_us": round(avg * 1e6, 2), "bytes_per_launch": jac_bytes,
+            "note": "achieved/frac use the CSR byte model of SURVEY §8d (12*nnz + 36*n); the kernel's own layout streams "
+                    "layout_bytes_per_launch, i.e. layout_GBps of real traffic",
+            "layout_bytes_per_launch": fmt_bytes, "layout_GBps": round(fmt_bytes / avg / 1e9, 1),
+            "layout_frac": round(fmt_bytes / avg / 1e9 / HBM_PEAK_GBS, 4),
         }
 
     # whole-iteration algorithmic bytes: V-cycle + SpMV + 2 dot + nrm2 + 3 axpy-type

@@ -92,12 +92,18 @@ int sparsh_setup(sparsh_handle h, const sparsh_params *p);
 int sparsh_set_stopping(sparsh_handle h, double tol, int max_iter, int check_every);
 
 /* Process-wide choice of the SpMV-type kernel family (A/B measurements; all families produce
- * bitwise identical results).  kind: 0 workgroup CSR-stream, 1 wave CSR-stream, 2 sliced-ELL mirror
- * where the operator is regular enough (falls back to 0 otherwise); vec: paired 16-B/8-B loads in
+ * bitwise identical results).  kind: 0 workgroup CSR-stream, 1 wave CSR-stream, 2 sliced-ELL mirror,
+ * 3 sliced-diagonal mirror (default); 2 and 3 fall back (3 -> 2 -> 0) where the operator does not
+ * qualify for the mirror; vec: paired 16-B/8-B loads in
  * the stream phase; nt: non-temporal loads for the matrix stream; remap: 0 none, 1 each XCD owns a
  * contiguous eighth of the row blocks, G > 1 groups of G row blocks dealt round-robin to the XCDs.
  * nt < 0 or remap < 0 selects the built-in per-operator policy (default). */
 int sparsh_set_kernel_config(int kind, int vec, int nt, int remap);
+
+/* Which layout the SpMV-type kernels of a level use under the current config (3 sliced diagonals,
+ * 2 sliced ELL, 1 wave CSR-stream, 0 workgroup CSR-stream) and how many entries it stores
+ * (padding included). */
+int sparsh_level_format(sparsh_handle h, int level, int *kind, long *stored_entries);
 
 /* Host half of sparsh_setup only (coarsening, Galerkin products, coarse factorisation); needs
  * no GPU.  Enables the inspection calls below; solvers still require sparsh_setup. */

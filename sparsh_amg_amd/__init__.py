@@ -80,6 +80,7 @@ def _load():
         "sparsh_setup_host": (C.c_int, [H, P(Params)]),
         "sparsh_set_stopping": (C.c_int, [H, C.c_double, C.c_int, C.c_int]),
         "sparsh_set_kernel_config": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+        "sparsh_level_format": (C.c_int, [H, C.c_int, c_int_p, C.POINTER(C.c_long)]),
         "sparsh_num_levels": (C.c_int, [H]),
         "sparsh_level_info": (C.c_int, [H, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p]),
         "sparsh_level_csr": (C.c_int, [H, C.c_int, C.c_int, c_int_p, c_int_p, c_dbl_p]),
@@ -152,7 +153,7 @@ def default_params(**kw) -> Params:
     return p
 
 
-def set_kernel_config(kind=2, vec=True, nt=-1, remap=-1):
+def set_kernel_config(kind=3, vec=True, nt=-1, remap=-1):
     """Select the SpMV-type kernel family (process-wide); see sparsh_set_kernel_config."""
     _check(lib.sparsh_set_kernel_config(int(kind), int(vec), int(nt), int(remap)))
 
@@ -238,6 +239,12 @@ class sp_matrix_mg:
         a = [C.c_int() for _ in range(4)]
         _check(lib.sparsh_level_info(self._h, level, *[C.byref(v) for v in a]))
         return dict(nrow=a[0].value, nnz=a[1].value, p_ncol=a[2].value, p_nnz=a[3].value)
+
+    def level_format(self, level):
+        """(kind, stored entries) of the layout the SpMV-type kernels use on this level."""
+        k, e = C.c_int(), C.c_long()
+        _check(lib.sparsh_level_format(self._h, level, C.byref(k), C.byref(e)))
+        return k.value, e.value
 
     def level_csr(self, level, which="A"):
         info = self.level_info(level)

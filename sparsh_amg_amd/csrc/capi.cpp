@@ -163,13 +163,38 @@ int sparsh_set_stopping(sparsh_handle h, double tol, int max_iter, int check_eve
 
 int sparsh_set_kernel_config(int kind, int vec, int nt, int remap)
 {
-    if (kind < 0 || kind > 2) return fail(SPARSH_EINVAL, "kind must be 0 (workgroup CSR-stream), 1 (wave CSR-stream) or 2 (sliced ELL)");
+    if (kind < 0 || kind > 3) return fail(SPARSH_EINVAL, "kind must be 0 (workgroup CSR-stream), 1 (wave CSR-stream), 2 (sliced ELL) or 3 (sliced diagonals)");
     KernelConfig &c = kernel_config();
     c.kind = kind;
     c.vec = vec != 0;
     c.nt = nt > 0;
     c.remap = remap < 0 ? 0 : remap;
     c.auto_policy = (nt < 0 || remap < 0);
+    return SPARSH_OK;
+}
+
+// which kernel family the SpMV-type operators of a level run with under the current config:
+// 3 sliced diagonals, 2 sliced ELL, 1 wave CSR-stream, 0 workgroup CSR-stream; bytes_per_entry =
+// what that layout streams per stored entry (values + indices), slots/entries incl. padding.
+int sparsh_level_format(sparsh_handle h, int level, int *kind, long *stored_entries)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    const DevCsr &A = h->eng->level(level).A;
+    const KernelConfig &c = kernel_config();
+    int k = 0;
+    long e = A.nnz;
+    if (c.kind == 3 && A.sd_val) {
+        k = 3;
+        e = A.sd_slots * 64;
+    } else if (c.kind >= 2 && A.sell_val) {
+        k = 2;
+        e = A.sell_entries;
+    } else if (c.kind == 1) {
+        k = 1;
+    }
+    if (kind) *kind = k;
+    if (stored_entries) *stored_entries = e;
     return SPARSH_OK;
 }
 

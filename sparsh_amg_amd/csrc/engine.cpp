@@ -123,6 +123,70 @@ bool upload_sell(Engine &E, const HostCsr &A, DevCsr &D)
     return D.slice_ptr && D.sell_col && D.sell_val;
 }
 
+// sliced-diagonal mirror; built only for square operators whose slices hold few distinct
+// diagonals (slots*64 <= 1.25 nnz) -- finite-difference / finite-volume stencils and their
+// pairwise-aggregated coarse operators.  Requires sorted columns (ascending offset == entry order).
+bool upload_sdia(Engine &E, const HostCsr &A, DevCsr &D)
+{
+    const int n = A.nrow;
+    if (n < 64 || A.ncol != A.nrow) return true;
+    const int nslice = (n + 63) / 64;
+    const long nnz = A.nnz();
+    std::vector<int> sp((size_t)nslice + 1, 0);
+    bool ok = true;
+#pragma omp parallel for schedule(static) reduction(&& : ok)
+    for (int s = 0; s < nslice; ++s) {
+        std::vector<int> offs;
+        const int r1 = std::min(n, (s + 1) * 64);
+        for (int r = s * 64; r < r1; ++r) {
+            for (int j = A.rowptr[r]; j < A.rowptr[r + 1]; ++j) {
+                offs.push_back(A.col[j] - r);
+                if (j > A.rowptr[r] && A.col[j] <= A.col[j - 1]) ok = false;  // unsorted / duplicate columns
+            }
+        }
+        std::sort(offs.begin(), offs.end());
+        offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
+        sp[(size_t)s + 1] = (int)offs.size();
+    }
+    if (!ok) return true;
+    long total = 0;
+    for (int s = 0; s < nslice; ++s) {
+        total += sp[(size_t)s + 1];
+        sp[(size_t)s + 1] = (int)total;
+        if (total * 64 > (1l << 31) - 64) return true;
+    }
+    if (total * 64 > nnz + nnz / 4) return true;  // too many sparse diagonals: keep ELL / CSR
+    std::vector<int> off((size_t)total);
+    std::vector<unsigned long long> mask((size_t)total, 0ull);
+    std::vector<double> val((size_t)total * 64, 0.0);
+#pragma omp parallel for schedule(static)
+    for (int s = 0; s < nslice; ++s) {
+        std::vector<int> offs;
+        const int r1 = std::min(n, (s + 1) * 64);
+        for (int r = s * 64; r < r1; ++r)
+            for (int j = A.rowptr[r]; j < A.rowptr[r + 1]; ++j) offs.push_back(A.col[j] - r);
+        std::sort(offs.begin(), offs.end());
+        offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
+        const int base = sp[s];
+        for (size_t d = 0; d < offs.size(); ++d) off[(size_t)base + d] = offs[d];
+        for (int r = s * 64; r < r1; ++r) {
+            const int lane = r & 63;
+            for (int j = A.rowptr[r]; j < A.rowptr[r + 1]; ++j) {
+                const int d = (int)(std::lower_bound(offs.begin(), offs.end(), A.col[j] - r) - offs.begin());
+                mask[(size_t)base + d] |= 1ull << lane;
+                val[((size_t)base + d) * 64 + lane] = A.val[j];
+            }
+        }
+    }
+    D.nslice = nslice;
+    D.sd_slots = total;
+    D.sd_ptr = upload(E, sp.data(), sp.size());
+    D.sd_off = upload(E, off.data(), off.size());
+    D.sd_mask = upload(E, mask.data(), mask.size());
+    D.sd_val = upload(E, val.data(), val.size());
+    return D.sd_ptr && D.sd_off && D.sd_mask && D.sd_val;
+}
+
 bool upload_csr(Engine &E, const HostCsr &A, DevCsr &D, bool with_sell)
 {
     D.nrow = A.nrow;
@@ -136,7 +200,7 @@ bool upload_csr(Engine &E, const HostCsr &A, DevCsr &D, bool with_sell)
     D.rowblk = upload(E, rb.data(), (size_t)D.nblk + 1);
     D.nwblk = build_waveblocks(A.nrow, A.rowptr, rb.data());
     D.waveblk = upload(E, rb.data(), (size_t)D.nwblk + 1);
-    if (with_sell && !upload_sell(E, A, D)) return false;
+    if (with_sell && (!upload_sell(E, A, D) || !upload_sdia(E, A, D))) return false;
     return D.rowptr && D.col && D.val && D.rowblk && D.waveblk;
 }
 

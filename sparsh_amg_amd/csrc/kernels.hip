@@ -108,12 +108,15 @@ struct RowOperands {
     double bi = 0.0, di = 1.0, xi = 0.0;
 };
 
-template <int OP>
+// LOAD_D = false: the kernel picks the diagonal out of the matrix stream it reads anyway (the
+// entry with col == row; same value as diag[], src/AMG_cpu_matrix.cpp:35-51) and skips the 8 B/row
+template <int OP, bool LOAD_D = true>
 __device__ __forceinline__ RowOperands load_row_operands(const CsrArgs &a, int row)
 {
     RowOperands o;
     if constexpr (op_needs_b(OP)) o.bi = a.b[row];
-    if constexpr (op_needs_d(OP)) o.di = a.d[row];
+    if constexpr (op_needs_d(OP) && LOAD_D) o.di = a.d[row];
+    if constexpr (op_needs_d(OP) && !LOAD_D) o.di = 0.0;  // a row without a diagonal entry keeps diag[] = 0
     if constexpr (op_needs_xi(OP)) o.xi = a.x[row];
     return o;
 }
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(kBlock) void csr_wave_kernel(const int *__restrict_
 // before the first add.
 template <int L, bool NT>
 __device__ __forceinline__ double sell_chunk(const int *__restrict__ cp, const double *__restrict__ vp,
-                                             const double *__restrict__ x, int k0, int len, double sum)
+                                             const double *__restrict__ x, int k0, int len, int row, double &dv, double sum)
 {
     int c[L];
     double v[L], xv[L];
@@ -357,26 +360,28 @@ __device__ __forceinline__ double sell_chunk(const int *__restrict__ cp, const d
 #pragma unroll
     for (int u = 0; u < L; ++u) {
         const double t = v[u] * xv[u];
-        sum = (k0 + u < len) ? sum + t : sum;
+        const bool on = k0 + u < len;
+        sum = on ? sum + t : sum;
+        dv = (on && c[u] == row) ? v[u] : dv;
     }
     return sum;
 }
 
 template <bool NT>
 __device__ __forceinline__ double sell_row(const int *__restrict__ cp, const double *__restrict__ vp,
-                                           const double *__restrict__ x, int slen, int len)
+                                           const double *__restrict__ x, int slen, int len, int row, double &dv)
 {
     double sum = 0.0;
     int k = 0;
-    for (; k + 8 <= slen; k += 8) sum = sell_chunk<8, NT>(cp, vp, x, k, len, sum);
+    for (; k + 8 <= slen; k += 8) sum = sell_chunk<8, NT>(cp, vp, x, k, len, row, dv, sum);
     switch (slen - k) {  // wave-uniform
-    case 7: sum = sell_chunk<7, NT>(cp, vp, x, k, len, sum); break;
-    case 6: sum = sell_chunk<6, NT>(cp, vp, x, k, len, sum); break;
-    case 5: sum = sell_chunk<5, NT>(cp, vp, x, k, len, sum); break;
-    case 4: sum = sell_chunk<4, NT>(cp, vp, x, k, len, sum); break;
-    case 3: sum = sell_chunk<3, NT>(cp, vp, x, k, len, sum); break;
-    case 2: sum = sell_chunk<2, NT>(cp, vp, x, k, len, sum); break;
-    case 1: sum = sell_chunk<1, NT>(cp, vp, x, k, len, sum); break;
+    case 7: sum = sell_chunk<7, NT>(cp, vp, x, k, len, row, dv, sum); break;
+    case 6: sum = sell_chunk<6, NT>(cp, vp, x, k, len, row, dv, sum); break;
+    case 5: sum = sell_chunk<5, NT>(cp, vp, x, k, len, row, dv, sum); break;
+    case 4: sum = sell_chunk<4, NT>(cp, vp, x, k, len, row, dv, sum); break;
+    case 3: sum = sell_chunk<3, NT>(cp, vp, x, k, len, row, dv, sum); break;
+    case 2: sum = sell_chunk<2, NT>(cp, vp, x, k, len, row, dv, sum); break;
+    case 1: sum = sell_chunk<1, NT>(cp, vp, x, k, len, row, dv, sum); break;
     default: break;
     }
     return sum;
@@ -402,9 +407,87 @@ __global__ __launch_bounds__(kBlock) void sell_kernel(int nrow, int nslice, int 
         RowOperands o;
         if (has_row) {
             len = rowptr[row + 1] - rowptr[row];
-            o = load_row_operands<OP>(a, row);
+            o = load_row_operands<OP, false>(a, row);
         }
-        const double sum = sell_row<NT>(scol + base + lane, sval + base + lane, a.x, slen, len);
+        const double sum = sell_row<NT>(scol + base + lane, sval + base + lane, a.x, slen, len, row, o.di);
+        if (has_row) acc = row_epilogue<OP>(a, row, sum, o);
+    }
+    if constexpr (op_reduces(OP)) {
+        const double t = block_sum(acc, red);
+        if (threadIdx.x == 0) a.partial[gid] = t;
+    }
+}
+
+// sliced diagonals: slot d of slice s holds, for every row r of the slice that has an entry in
+// column r + off[d], its value.  Slots are sorted by offset, i.e. by column, so a row's present
+// slots are visited in exactly its CSR entry order; absent slots are skipped by the lane mask.
+template <int L, bool NT>
+__device__ __forceinline__ double sdia_chunk(const int *__restrict__ off, const unsigned long long *__restrict__ mask,
+                                             const double *__restrict__ vp, const double *__restrict__ x, int d0, int row,
+                                             int lane, double &dv, double sum)
+{
+    double v[L], xv[L];
+    bool on[L];
+    int oo[L];
+#pragma unroll
+    for (int u = 0; u < L; ++u) {
+        const int o = __builtin_amdgcn_readfirstlane(off[d0 + u]);
+        oo[u] = o;
+        const unsigned long long m = mask[d0 + u];  // wave-uniform address
+        on[u] = (m >> lane) & 1ull;
+        v[u] = ld_stream<NT>(vp + (size_t)(d0 + u) * 64);
+        xv[u] = x[on[u] ? row + o : row];  // clamp absent lanes onto a valid address
+    }
+#pragma unroll
+    for (int u = 0; u < L; ++u) {
+        const double t = v[u] * xv[u];
+        sum = on[u] ? sum + t : sum;
+        if (oo[u] == 0) dv = on[u] ? v[u] : dv;  // wave-uniform test: the main diagonal's slot
+    }
+    return sum;
+}
+
+template <bool NT>
+__device__ __forceinline__ double sdia_row(const int *__restrict__ off, const unsigned long long *__restrict__ mask,
+                                           const double *__restrict__ vp, const double *__restrict__ x, int nd, int row, int lane,
+                                           double &dv)
+{
+    double sum = 0.0;
+    int d = 0;
+    for (; d + 8 <= nd; d += 8) sum = sdia_chunk<8, NT>(off, mask, vp, x, d, row, lane, dv, sum);
+    switch (nd - d) {  // wave-uniform
+    case 7: sum = sdia_chunk<7, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    case 6: sum = sdia_chunk<6, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    case 5: sum = sdia_chunk<5, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    case 4: sum = sdia_chunk<4, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    case 3: sum = sdia_chunk<3, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    case 2: sum = sdia_chunk<2, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    case 1: sum = sdia_chunk<1, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    default: break;
+    }
+    return sum;
+}
+
+template <int OP, bool NT, int TAG>
+__global__ __launch_bounds__(kBlock) void sdia_kernel(int nrow, int nslice, int ngroups, int remap, const int *__restrict__ sd_ptr,
+                                                       const int *__restrict__ sd_off, const unsigned long long *__restrict__ sd_mask,
+                                                       const double *__restrict__ sd_val, CsrArgs a)
+{
+    __shared__ double red[kBlock / 64];
+    const int gid = remap ? xcd_remap(blockIdx.x, ngroups, remap) : blockIdx.x;
+    if (gid >= ngroups) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int sl = gid * (kBlock / 64) + w;
+    double acc = 0.0;
+    if (sl < nslice) {
+        int row = sl * 64 + lane;
+        const bool has_row = row < nrow;
+        if (!has_row) row = nrow - 1;  // tail lanes of the last slice: masks are clear, keep addresses valid
+        const int s0 = __builtin_amdgcn_readfirstlane(sd_ptr[sl]);
+        const int nd = __builtin_amdgcn_readfirstlane(sd_ptr[sl + 1]) - s0;
+        RowOperands o;
+        if (has_row) o = load_row_operands<OP, false>(a, row);
+        const double sum = sdia_row<NT>(sd_off + s0, sd_mask + s0, sd_val + (size_t)s0 * 64 + lane, a.x, nd, row, lane, o.di);
         if (has_row) acc = row_epilogue<OP>(a, row, sum, o);
     }
     if constexpr (op_reduces(OP)) {
@@ -419,7 +502,17 @@ template <int OP, int TAG>
 int launch_csr_tagged(const DevCsr &A, const CsrArgs &a, bool nt, int remap, hipStream_t st)
 {
     const KernelConfig &c = g_cfg;
-    if (c.kind == 2 && A.sell_val) {
+    if (c.kind == 3 && A.sd_val) {
+        const int ngroups = (A.nslice + 3) / 4;
+        if (ngroups <= 0) return 0;
+        const int grid = remap_grid(ngroups, remap);
+        if (nt)
+            hipLaunchKernelGGL((sdia_kernel<OP, true, TAG>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.nslice, ngroups, remap, A.sd_ptr, A.sd_off, A.sd_mask, A.sd_val, a);
+        else
+            hipLaunchKernelGGL((sdia_kernel<OP, false, TAG>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.nslice, ngroups, remap, A.sd_ptr, A.sd_off, A.sd_mask, A.sd_val, a);
+        return ngroups;
+    }
+    if (c.kind >= 2 && A.sell_val) {
         const int ngroups = (A.nslice + 3) / 4;
         if (ngroups <= 0) return 0;
         const int grid = remap_grid(ngroups, remap);

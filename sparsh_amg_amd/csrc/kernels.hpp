@@ -28,11 +28,21 @@ struct DevCsr {
     int *sell_col = nullptr;
     double *sell_val = nullptr;
     long sell_entries = 0;
+    // optional sliced-diagonal mirror for stencil-like operators: per slice of 64 rows the distinct
+    // offsets (col - row) are stored once, values sit column-major by offset slot, a 64-bit lane
+    // mask per slot says which rows really hold an entry there.  No per-entry column index: 8 B
+    // instead of 12 B per stored entry.
+    int *sd_ptr = nullptr;              // nslice+1: first slot of every slice
+    int *sd_off = nullptr;              // per slot: col - row
+    unsigned long long *sd_mask = nullptr;  // per slot: lanes (rows of the slice) that hold an entry
+    double *sd_val = nullptr;           // per slot: 64 values, lane-major
+    long sd_slots = 0;
 };
 
 // run-time choice of the SpMV-type kernel family (A/B measurements; defaults = the fastest measured)
 struct KernelConfig {
-    int kind = 2;       // 0 workgroup CSR-stream, 1 wave CSR-stream, 2 sliced-ELL where available (else 0)
+    int kind = 3;       // 0 workgroup CSR-stream, 1 wave CSR-stream, 2 sliced ELL, 3 sliced diagonals; 2 and 3 fall
+                        // back (3 -> 2 -> 0) where the operator does not qualify for the mirror
     bool vec = true;    // phase 1 reads two entries per lane (16-B val / 8-B col loads)
     bool auto_policy = true;  // choose nt / remap per operator from its size (overrides the two below)
     bool nt = true;     // non-temporal loads for the matrix stream

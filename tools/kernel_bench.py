@@ -31,7 +31,7 @@ def main():
     if a.remaps:
         print(f"{'config':28s} {'op':8s} {'lvl':>3s} {'us':>9s} {'GB/s':>8s} {'frac8T':>7s}")
         for rnd in range(a.rounds):
-            for (k, v) in ((2, 0), (0, 1)):
+            for (k, v) in ((3, 0), (2, 0)):
                 for nt in (1, 0):
                     for rm in a.remaps:
                         sa.set_kernel_config(kind=k, vec=v, nt=nt, remap=rm)
@@ -47,7 +47,7 @@ def main():
         return
     if a.variants:
         print(f"{'config':28s} {'op':8s} {'lvl':>3s} {'us':>9s} {'GB/s':>8s} {'frac8T':>7s}")
-        cfgs = [(k, v, nt, rm) for k in (0, 1, 2) for v in ((0, 1) if k < 2 else (0,)) for nt in (1, 0) for rm in (1, 0)]
+        cfgs = [(k, v, nt, rm) for k in (0, 1, 2, 3) for v in ((0, 1) if k < 2 else (0,)) for nt in (1, 0) for rm in (1, 16)]
         for rnd in range(a.rounds):
             for (k, v, nt, rm) in cfgs:
                 sa.set_kernel_config(kind=k, vec=v, nt=nt, remap=rm)

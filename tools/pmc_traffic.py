@@ -47,8 +47,9 @@ def collect(d):
             key = "dot"
         elif "copy_int_kernel" in name:
             key = "copy_int"
-        elif ("sell_kernel<2" in name or "csr_block_kernel<2" in name) and ", 1>" in name:
+        elif ("sdia_kernel<2" in name or "sell_kernel<2" in name or "csr_block_kernel<2" in name) and ", 1>" in name:
             key = "jacobi"
+            out["_kind"] = [3.0 if "sdia_kernel" in name else (2.0 if "sell_kernel" in name else 0.0)]
         if key:
             out.setdefault(key, []).append(float(r["Counter_Value"]) * 1024.0)
     return {k: sum(v) / len(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
@@ -66,12 +67,16 @@ def summarize(fetch_dir, write_dir, out_path):
     f4 = known_read["copy_int"] / fetch["copy_int"]  # 4-byte-per-lane loads
     wf8 = known_write["axpby"] / write["axpby"]
     wf4 = known_write["copy_int"] / write["copy_int"]
-    # Jacobi kernel streams: 4-byte loads = column indices (padded ELL) + 2 rowptr reads (one line);
-    # 8-byte loads = values, b, d, x_i, gathered x.  raw = bytes4/f4 + bytes8/f8  ->  solve for bytes8.
+    # Jacobi kernel streams.  sliced ELL: 4-byte loads = column indices (padded) + rowptr; sliced
+    # diagonals: no per-entry index (offsets/masks are per slot: < 1.5 % of the bytes, counted with
+    # the 8-byte streams).  raw = bytes4/f4 + bytes8/f8  ->  solve for bytes8.
     pad_nnz = 7 * n
-    bytes4 = 4 * pad_nnz + 4 * n
+    kind = int(fetch.pop("_kind", 2.0))
+    cnt.pop("_kind", None)
+    bytes4 = (4 * pad_nnz + 4 * n) if kind == 2 else 0
     bytes8 = (fetch["jacobi"] - bytes4 / f4) * f8
     read_total = bytes4 + bytes8
+    nstream8 = 8 * pad_nnz + (16 * n if kind == 2 else 8 * n)  # values + b (+ d for ELL before the diagonal pick-up)
     alg = 12 * nnz + 36 * n
     res = {
         "_how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); counter KiB -> bytes; per-width correction from "
@@ -84,7 +89,8 @@ def summarize(fetch_dir, write_dir, out_path):
         "jacobi_fine_bytes_per_launch": read_total + write["jacobi"] * wf8,
         "jacobi_fine_algorithmic_bytes": alg,
         "ratio_traffic_over_algorithmic": (read_total + write["jacobi"] * wf8) / alg,
-        "x_vector_fetches_per_entry": (bytes8 - 8 * pad_nnz - 16 * n) / (8 * n),
+        "kernel_family": {3: "sdia_kernel (sliced diagonals)", 2: "sell_kernel (sliced ELL)", 0: "csr_block_kernel"}.get(kind),
+        "x_vector_fetches_per_entry": (bytes8 - 8 * pad_nnz - 8 * n) / (8 * n),
     }
     with open(out_path, "w") as f:
         json.dump(res, f, indent=1)
