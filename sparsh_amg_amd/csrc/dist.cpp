@@ -82,6 +82,7 @@ LocalOp extract_local(const HostCsr &M, const Partition &rowsP, const Partition 
     for (int i = 0; i <= nrows; ++i) A.rp_store[i] = M.rowptr[rlo + i] - j0;
     A.col_store.assign(M.col + j0, M.col + j1);
     A.val_store.assign(M.val + j0, M.val + j1);
+    A.grow0 = rlo;
     if (colsP.replicated) {  // the whole input vector is present on every rank: keep global columns
         A.ncol = M.ncol;
         L.plan.nloc = M.ncol;
@@ -108,6 +109,7 @@ LocalOp extract_local(const HostCsr &M, const Partition &rowsP, const Partition 
         L.plan.recv.push_back({peer, (int)q, (int)(e - q)});
         q = e;
     }
+    A.gcol_store = A.col_store;  // global columns, before renumbering
     // renumber columns
     for (int &c : A.col_store) {
         if (c >= clo && c < chi)

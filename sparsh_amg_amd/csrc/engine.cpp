@@ -123,30 +123,43 @@ bool upload_sell(Engine &E, const HostCsr &A, DevCsr &D)
     return D.slice_ptr && D.sell_col && D.sell_val;
 }
 
-// sliced-diagonal mirror; built only for square operators whose slices hold few distinct
-// diagonals (slots*64 <= 1.25 nnz) -- finite-difference / finite-volume stencils and their
-// pairwise-aggregated coarse operators.  Requires sorted columns (ascending offset == entry order).
+// sliced-diagonal mirror; built only for operators whose slices hold few distinct diagonals
+// (slots*64 <= 1.25 nnz) -- finite-difference / finite-volume stencils and their pairwise-
+// aggregated coarse operators.  A slot is one (offset) diagonal inside a slice; slots are ordered
+// by the entries' GLOBAL column offset, which is each row's entry order (sorted global columns),
+// so the kernel adds a row's products in CSR order.  For a rank-local block the address offset
+// (local col - local row) differs from the global one on halo columns; both are kept.
 bool upload_sdia(Engine &E, const HostCsr &A, DevCsr &D)
 {
     const int n = A.nrow;
-    if (n < 64 || A.ncol != A.nrow) return true;
+    if (n < 64) return true;
+    const bool local = !A.gcol_store.empty();
+    if (!local && A.ncol != A.nrow) return true;
+    const int *gcol = local ? A.gcol_store.data() : A.col;
     const int nslice = (n + 63) / 64;
     const long nnz = A.nnz();
+    using Slot = std::pair<int, int>;  // (global offset = ordering key, local offset = address offset)
+    auto slice_slots = [&](int s, std::vector<Slot> &slots, bool &sorted) {
+        slots.clear();
+        const int r1 = std::min(n, (s + 1) * 64);
+        for (int r = s * 64; r < r1; ++r) {
+            for (int j = A.rowptr[r]; j < A.rowptr[r + 1]; ++j) {
+                slots.emplace_back(gcol[j] - (A.grow0 + r), A.col[j] - r);
+                if (j > A.rowptr[r] && gcol[j] <= gcol[j - 1]) sorted = false;  // unsorted / duplicate columns
+            }
+        }
+        std::sort(slots.begin(), slots.end());
+        slots.erase(std::unique(slots.begin(), slots.end()), slots.end());
+    };
     std::vector<int> sp((size_t)nslice + 1, 0);
     bool ok = true;
 #pragma omp parallel for schedule(static) reduction(&& : ok)
     for (int s = 0; s < nslice; ++s) {
-        std::vector<int> offs;
-        const int r1 = std::min(n, (s + 1) * 64);
-        for (int r = s * 64; r < r1; ++r) {
-            for (int j = A.rowptr[r]; j < A.rowptr[r + 1]; ++j) {
-                offs.push_back(A.col[j] - r);
-                if (j > A.rowptr[r] && A.col[j] <= A.col[j - 1]) ok = false;  // unsorted / duplicate columns
-            }
-        }
-        std::sort(offs.begin(), offs.end());
-        offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
-        sp[(size_t)s + 1] = (int)offs.size();
+        std::vector<Slot> slots;
+        bool sorted = true;
+        slice_slots(s, slots, sorted);
+        ok = ok && sorted;
+        sp[(size_t)s + 1] = (int)slots.size();
     }
     if (!ok) return true;
     long total = 0;
@@ -161,18 +174,17 @@ bool upload_sdia(Engine &E, const HostCsr &A, DevCsr &D)
     std::vector<double> val((size_t)total * 64, 0.0);
 #pragma omp parallel for schedule(static)
     for (int s = 0; s < nslice; ++s) {
-        std::vector<int> offs;
-        const int r1 = std::min(n, (s + 1) * 64);
-        for (int r = s * 64; r < r1; ++r)
-            for (int j = A.rowptr[r]; j < A.rowptr[r + 1]; ++j) offs.push_back(A.col[j] - r);
-        std::sort(offs.begin(), offs.end());
-        offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
+        std::vector<Slot> slots;
+        bool sorted = true;
+        slice_slots(s, slots, sorted);
         const int base = sp[s];
-        for (size_t d = 0; d < offs.size(); ++d) off[(size_t)base + d] = offs[d];
+        for (size_t d = 0; d < slots.size(); ++d) off[(size_t)base + d] = slots[d].second;
+        const int r1 = std::min(n, (s + 1) * 64);
         for (int r = s * 64; r < r1; ++r) {
             const int lane = r & 63;
             for (int j = A.rowptr[r]; j < A.rowptr[r + 1]; ++j) {
-                const int d = (int)(std::lower_bound(offs.begin(), offs.end(), A.col[j] - r) - offs.begin());
+                const Slot key(gcol[j] - (A.grow0 + r), A.col[j] - r);
+                const int d = (int)(std::lower_bound(slots.begin(), slots.end(), key) - slots.begin());
                 mask[(size_t)base + d] |= 1ull << lane;
                 val[((size_t)base + d) * 64 + lane] = A.val[j];
             }

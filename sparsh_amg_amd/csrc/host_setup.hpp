@@ -20,6 +20,10 @@ struct HostCsr {
     // storage when owning
     std::vector<int> rp_store, col_store;
     std::vector<double> val_store;
+    // rank-local blocks of a partitioned operator only: the global column of every entry and the
+    // global index of local row 0 (layout builders need the original entry order)
+    std::vector<int> gcol_store;
+    int grow0 = 0;
 
     int nnz() const { return rowptr ? rowptr[nrow] : 0; }
     void adopt()

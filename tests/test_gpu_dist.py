@@ -31,7 +31,7 @@ def run_ranks(rp, ci, v, b, G, method, **kw):
                 h, rc = A.vcycle(b[lo:hi].copy(), x, iterations=3)
             else:
                 h, rc = A.solve(method, b[lo:hi].copy(), x)
-            out[r] = (lo, hi, rep, x, h, rc, [A.local_range(l) for l in range(A.nlevels)])
+            out[r] = (lo, hi, rep, x, h, rc, [A.local_range(l) for l in range(A.nlevels)], A.level_format(0)[0])
             A.close()
         except Exception as e:  # noqa: BLE001
             errs.append((r, repr(e)))
@@ -102,6 +102,8 @@ def test_fixed_cycles_bitwise_rows():
     res = run_ranks(rp, ci, v, b, 3, "vcycle3", replicate_rows=2000)
     x = np.concatenate([r[3] for r in sorted(res, key=lambda t: t[0])])
     assert np.array_equal(x, x1)
+    # rank-local blocks of a stencil operator keep the sliced-diagonal layout (halo columns included)
+    assert all(r[7] == 3 for r in res), [r[7] for r in res]
 
 
 def test_everything_replicated_small_problem():
