@@ -223,6 +223,16 @@ def main():
     hfull, it_full, sec_full, rc_full = A.solve_dev("pcg", bd, xd)
     full = {"iterations": it_full, "seconds": round(sec_full, 4), "final_residual": float(hfull[-1]) if len(hfull) else None, "rc": rc_full}
 
+    # the boundary hands over host buffers (reference API): same full solve through sparsh_solve,
+    # which adds H2D of b and x and D2H of x over PCIe -- reported, never used as `value`
+    if world == 1 and mode == "single":
+        xh = np.zeros(n)
+        t_h = time.perf_counter()
+        hh, rc_h = A.solve("pcg", b, xh)
+        t_h = time.perf_counter() - t_h
+        full["host_buffer_path_seconds"] = round(t_h, 4)
+        full["host_buffer_path_iterations_per_s"] = round(len(hh) / t_h, 2)
+
     # multi-GPU parity: rank 0 repeats the same iterations on ONE GPU (fresh handle, no transport)
     # and compares residual histories; the other ranks wait at the barrier below.
     parity = None

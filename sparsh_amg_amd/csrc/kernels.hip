@@ -834,7 +834,10 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(int code, int mode,
     case FIN_BICG_OMEGA: {
         scal[S_ASS] = s0;
         scal[S_ASAS] = s1;
-        scal[S_OMEGA1] = s0 / s1;
+        // lucky breakdown: s = 0 after the half step (exact preconditioner, tiny systems) makes
+        // As.As = 0; the reference divides 0/0 there and returns NaN.  omega = 0 keeps x and ends
+        // the loop with r = s = 0.
+        scal[S_OMEGA1] = (s1 == 0.0) ? 0.0 : s0 / s1;
     } break;
     case FIN_BICG_BETA: {
         double beta = s0 / scal[S_ALPHA1];

@@ -1,0 +1,102 @@
+// AddressSanitizer / UBSan driver for the product's host code (CPU only; GPU ASan is not
+// available on the pool).  One translation unit: host_setup.cpp + dist.cpp.
+#include "../../sparsh_amg_amd/csrc/host_setup.cpp"
+#include "../../sparsh_amg_amd/csrc/dist.cpp"
+
+#include <cstdio>
+#include <cstdlib>
+
+using namespace sparsh;
+
+static HostCsr poisson3d(int n)
+{
+    HostCsr A;
+    const int N = n * n * n;
+    A.nrow = A.ncol = N;
+    A.rp_store.assign((size_t)N + 1, 0);
+    for (int k = 0; k < n; ++k)
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i) {
+                const int r = i + n * (j + n * k);
+                auto add = [&](int c, double v) {
+                    A.col_store.push_back(c);
+                    A.val_store.push_back(v);
+                };
+                if (k > 0) add(r - n * n, -1);
+                if (j > 0) add(r - n, -1);
+                if (i > 0) add(r - 1, -1);
+                add(r, 6);
+                if (i < n - 1) add(r + 1, -1);
+                if (j < n - 1) add(r + n, -1);
+                if (k < n - 1) add(r + n * n, -1);
+                A.rp_store[(size_t)r + 1] = (int)A.col_store.size();
+            }
+    A.adopt();
+    return A;
+}
+
+static std::vector<double> spmv(const HostCsr &A, const std::vector<double> &x)
+{
+    std::vector<double> y((size_t)A.nrow);
+    for (int i = 0; i < A.nrow; ++i) {
+        double s = 0;
+        for (int j = A.rowptr[i]; j < A.rowptr[i + 1]; ++j) s += A.val[j] * x[(size_t)A.col[j]];
+        y[(size_t)i] = s;
+    }
+    return y;
+}
+
+int main()
+{
+    HostCsr A = poisson3d(18);
+    for (int coarsening = 0; coarsening < 2; ++coarsening) {
+        SetupParams sp;
+        sp.limit_upper = 400;
+        sp.limit_lower = 200;
+        sp.coarsening = coarsening;
+        sp.print = false;
+        sp.host_threads = 4;
+        HostHierarchy H;
+        if (!build_hierarchy(A, sp, H)) {
+            std::printf("setup failed: %s\n", H.error.c_str());
+            return 1;
+        }
+        // inverse check
+        const HostCsr &AL = H.levels.back().A;
+        std::vector<double> e((size_t)AL.nrow, 1.0), y((size_t)AL.nrow, 0.0);
+        for (int i = 0; i < AL.nrow; ++i)
+            for (int j = 0; j < AL.nrow; ++j) y[(size_t)i] += H.coarse_inverse[(size_t)i * AL.nrow + j] * e[(size_t)j];
+        std::vector<double> chk = spmv(AL, y);
+        for (double v : chk)
+            if (std::fabs(v - 1.0) > 1e-9) {
+                std::printf("inverse check failed\n");
+                return 2;
+            }
+        // partition + local extraction for 3 ranks on the two finest levels
+        const int G = 3;
+        std::vector<Partition> parts;
+        parts.push_back(make_partition(H.levels[0].A.nrow, G));
+        parts.push_back(coarse_partition(H.levels[0].R, parts[0]));
+        for (int l = 0; l < 2 && l + 1 < (int)H.levels.size(); ++l) {
+            const HostCsr &M = H.levels[l].A;
+            std::vector<double> x((size_t)M.ncol);
+            for (size_t i = 0; i < x.size(); ++i) x[i] = std::sin(0.37 * (double)i);
+            std::vector<double> ref = spmv(M, x);
+            for (int r = 0; r < G; ++r) {
+                LocalOp L = extract_local(M, parts[l], parts[l], r);
+                std::vector<double> xl((size_t)L.plan.nloc + L.plan.nhalo);
+                const int lo = parts[l].lo(r);
+                for (int i = 0; i < L.plan.nloc; ++i) xl[(size_t)i] = x[(size_t)(lo + i)];
+                for (int i = 0; i < L.plan.nhalo; ++i) xl[(size_t)(L.plan.nloc + i)] = x[(size_t)L.plan.halo_global[(size_t)i]];
+                std::vector<double> yl = spmv(L.M, xl);
+                for (int i = 0; i < L.M.nrow; ++i)
+                    if (yl[(size_t)i] != ref[(size_t)(lo + i)]) {
+                        std::printf("local spmv mismatch\n");
+                        return 3;
+                    }
+            }
+        }
+    }
+    std::printf("ASAN_HOST_OK\n");
+    return 0;
+}
