@@ -108,6 +108,7 @@ def main():
         # independent replicas, and the record says so.
         ok, err = 1, ""
         try:
+            sa.set_device(local_rank)
             uid = [sa.comm_unique_id() if rank == 0 else None]
             if dist is not None:
                 dist.broadcast_object_list(uid, src=0)

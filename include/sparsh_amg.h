@@ -193,6 +193,7 @@ int sparsh_profile_read(sparsh_handle h, double *out4);
  * (e.g. a torch.distributed broadcast), every rank calls sparsh_comm_init_rccl BEFORE
  * sparsh_setup.  After setup, vectors passed to the *_dev entry points are the rank's own block
  * [lo, hi) of level 0 (sparsh_local_range). */
+int sparsh_set_device(int device); /* make `device` current for this thread (call before sparsh_comm_init_rccl) */
 int sparsh_comm_unique_id(char id128[128]);
 int sparsh_comm_init_rccl(sparsh_handle h, const char id128[128], int rank, int nranks);
 int sparsh_local_range(sparsh_handle h, int level, int *lo, int *hi, int *replicated);

@@ -89,6 +89,7 @@ def _load():
         "sparsh_vcycle": (C.c_int, [H, c_dbl_p, c_dbl_p, C.c_int, c_dbl_p, C.c_int, c_int_p]),
         "sparsh_solve": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, C.c_int, c_int_p]),
         "sparsh_solve_dev": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_int, c_dbl_p, C.c_int, c_int_p, c_dbl_p]),
+        "sparsh_set_device": (C.c_int, [C.c_int]),
         "sparsh_comm_unique_id": (C.c_int, [C.c_char_p]),
         "sparsh_comm_init_rccl": (C.c_int, [H, C.c_char_p, C.c_int, C.c_int]),
         "sparsh_local_range": (C.c_int, [H, C.c_int, c_int_p, c_int_p, c_int_p]),
@@ -156,6 +157,10 @@ def default_params(**kw) -> Params:
 def set_kernel_config(kind=3, vec=True, nt=-1, remap=-1):
     """Select the SpMV-type kernel family (process-wide); see sparsh_set_kernel_config."""
     _check(lib.sparsh_set_kernel_config(int(kind), int(vec), int(nt), int(remap)))
+
+
+def set_device(device: int):
+    _check(lib.sparsh_set_device(device))
 
 
 def comm_unique_id() -> bytes:

@@ -277,6 +277,14 @@ int sparsh_solve_dev(sparsh_handle h, int method, const double *b_dev, double *x
 
 // ---- multi-GPU ----
 
+int sparsh_set_device(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(SPARSH_ENODEV, "no HIP device visible");
+    if (hipSetDevice(device % n) != hipSuccess) return fail(SPARSH_ENODEV, "hipSetDevice failed");
+    return SPARSH_OK;
+}
+
 int sparsh_comm_unique_id(char id128[128])
 {
     std::string err;

@@ -52,15 +52,38 @@ def poisson3d(n: int, ny: int | None = None, nz: int | None = None):
     return _stencil_csr((n, ny or n, nz or n), 6.0)
 
 
-def fem_unstructured(npts: int = 525825, seed: int = 20240607, dt: float = 1e-2):
+def _morton_order(pts):
+    """Z-order (Morton) rank of 2D points in the unit square, 16 bits per axis."""
+    q = np.minimum((pts * 65536.0).astype(np.uint64), 65535)
+
+    def spread(v):
+        v = (v | (v << 8)) & 0x00FF00FF
+        v = (v | (v << 4)) & 0x0F0F0F0F
+        v = (v | (v << 2)) & 0x33333333
+        v = (v | (v << 1)) & 0x55555555
+        return v
+
+    return np.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1), kind="stable")
+
+
+def fem_unstructured(npts: int = 525825, seed: int = 20240607, dt: float = 1e-2, ordering: str = "morton"):
     """P1-FEM  M + dt*K  on a Delaunay triangulation of random points in the unit square:
     SPD, irregular 3..12+ nnz/row.  Stand-in for SuiteSparse parabolic_fem (configs[4]),
-    which cannot be fetched offline."""
+    which cannot be fetched offline.
+
+    ordering="morton" numbers the nodes along a space-filling curve, the kind of locality a mesh
+    generator's numbering has (neighbouring nodes get nearby indices); ordering="random" keeps the
+    random point order: every x-gather of a row lands on an unrelated cache line -- a worst case
+    no mesh file exhibits, kept as a gather stress."""
     from scipy.spatial import Delaunay
     import scipy.sparse as sp
 
     rng = np.random.default_rng(seed)
     pts = rng.random((npts, 2))
+    if ordering == "morton":
+        pts = pts[_morton_order(pts)]
+    elif ordering != "random":
+        raise ValueError("ordering must be 'morton' or 'random'")
     tri = Delaunay(pts).simplices.astype(np.int64)  # T x 3
     p0, p1, p2 = pts[tri[:, 0]], pts[tri[:, 1]], pts[tri[:, 2]]
     e1, e2 = p1 - p0, p2 - p0

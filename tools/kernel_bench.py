@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--n", type=int, default=216)
     ap.add_argument("--dim", type=int, default=3)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--ordering", default="morton")
+    ap.add_argument("--fem", type=int, default=0, help="use the unstructured P1-FEM stand-in with this many points")
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--cfg", type=int, nargs=4, default=None, metavar=("KIND", "VEC", "NT", "REMAP"))
     ap.add_argument("--remaps", type=int, nargs="*", default=None, help="sweep XCD remap modes for the Jacobi kernel")
@@ -24,7 +26,10 @@ def main():
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--vlevels", type=int, nargs="*", default=[0, 2, 4])
     a = ap.parse_args()
-    rp, ci, v = problems.poisson3d(a.n) if a.dim == 3 else problems.poisson2d(a.n)
+    if a.fem:
+        rp, ci, v = problems.fem_unstructured(a.fem, ordering=a.ordering)
+    else:
+        rp, ci, v = problems.poisson3d(a.n) if a.dim == 3 else problems.poisson2d(a.n)
     A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, print_solve=0))
     if a.cfg:
         sa.set_kernel_config(*a.cfg)
@@ -62,6 +67,7 @@ def main():
                         print(f"kind={k} vec={v} nt={nt} remap={rm} r{rnd:<3d} {op:8s} {l:3d} {sec * 1e6:9.1f} {gbs:8.1f} {gbs / 8000:7.3f}", flush=True)
         sa.set_kernel_config()
         return
+    print("level formats (3 sliced diagonals, 2 sliced ELL, 0 CSR-stream):", [A.level_format(l)[0] for l in range(A.nlevels)])
     print(f"{'op':10s} {'lvl':>3s} {'rows':>10s} {'nnz':>10s} {'us':>9s} {'GB/s':>8s} {'frac8T':>7s}")
     for l in range(min(a.levels, A.nlevels)):
         i = A.level_info(l)
