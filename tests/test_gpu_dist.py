@@ -113,3 +113,29 @@ def test_everything_replicated_small_problem():
     res = run_ranks(rp, ci, v, b, 2, "pcg")  # default replicate_rows > n: every rank solves it all
     assert all(r[2] for r in res) and all(r[1] - r[0] == n for r in res)
     assert np.array_equal(res[0][3], res[1][3])
+
+
+def test_eight_ranks_deep_partition():
+    """8 virtual ranks, five partitioned levels (forward and backward HEM sweeps alternate, so the
+    coarse blocks are handed out in alternating rank order), PCG history vs one rank."""
+    rp, ci, v = problems.poisson3d(48)
+    n = len(rp) - 1
+    b = np.random.default_rng(3).standard_normal(n)
+    A1 = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET))
+    x1 = np.zeros(n)
+    h1, _ = A1.solve("pcg", b, x1)
+    res = run_ranks(rp, ci, v, b, 8, "pcg", replicate_rows=4000)
+    levels = res[0][6]
+    assert sum(1 for (lo, hi, rep) in levels if not rep) >= 4
+    # the rank owning the first rows of level 1 is the one owning the first rows of level 0
+    # (forward sweep), while level 2 (backward sweep on level 1) is handed out in reverse
+    first0 = min(range(8), key=lambda r: res[r][6][0][0])
+    first1 = min(range(8), key=lambda r: res[r][6][1][0])
+    first2 = min(range(8), key=lambda r: res[r][6][2][0])
+    assert first0 == first1 and first2 != first1
+    x = np.concatenate([r[3] for r in sorted(res, key=lambda t: t[0])])
+    h = res[0][4]
+    assert len(h) == len(h1)
+    tol = np.where(h1 >= 1e-6 * h1[0], 1e-8, 1e-4)
+    assert np.all(np.abs(h - h1) <= tol * h1)
+    assert np.linalg.norm(x - x1) <= 1e-8 * np.linalg.norm(x1)
