@@ -96,7 +96,7 @@ def main():
     t_gen = time.time() - t_gen
 
     # tol = 0: the loop never stops early, so exactly W + K iterations run (the real solve
-    # converges to 1e-8 in ~25 iterations; reported separately as config.iters_to_tol)
+    # converges to 1e-8 in ~41 iterations; reported separately as config.full_solve_to_1e-8)
     host_threads = max(1, sa.host_cpus() // max(1, local_world))
     prm = sa.default_params(print_setup=0, print_solve=0, tol=0.0, device=local_rank, check_every=1 << 30, host_threads=host_threads)
     A = sa.sp_matrix_mg(rp, ci, v)

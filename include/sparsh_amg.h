@@ -125,6 +125,9 @@ double sparsh_setup_seconds(sparsh_handle h);
  * hist[k] = residual after cycle k+1 (the value the reference prints). */
 int sparsh_vcycle(sparsh_handle h, const double *b, double *x, int iterations, double *hist, int hist_cap, int *ncycles);
 
+/* Same with b/x already in HBM: AMG_GPU1_solver::AMG_Solve (src/AMG_gpu_phases_2.cu:96-240). */
+int sparsh_vcycle_dev(sparsh_handle h, const double *b_dev, double *x_dev, int iterations, double *hist, int hist_cap, int *ncycles);
+
 /* The 17 solver entry points of include/AMG.hpp:40-85 reduce to five methods (SPARSH_*).
  * x: initial guess in, solution out.  hist[k] = residual the reference prints at step k. */
 int sparsh_solve(sparsh_handle h, int method, const double *b, double *x, double *hist, int hist_cap, int *iters);

@@ -87,6 +87,7 @@ def _load():
         "sparsh_coarse_inverse": (C.c_int, [H, c_dbl_p]),
         "sparsh_setup_seconds": (C.c_double, [H]),
         "sparsh_vcycle": (C.c_int, [H, c_dbl_p, c_dbl_p, C.c_int, c_dbl_p, C.c_int, c_int_p]),
+        "sparsh_vcycle_dev": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int, c_dbl_p, C.c_int, c_int_p]),
         "sparsh_solve": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, C.c_int, c_int_p]),
         "sparsh_solve_dev": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_int, c_dbl_p, C.c_int, c_int_p, c_dbl_p]),
         "sparsh_set_device": (C.c_int, [C.c_int]),

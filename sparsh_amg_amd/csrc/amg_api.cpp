@@ -17,6 +17,8 @@
 #include "../../include/sparsh_amg.h"
 // AMG.hpp defines short macros (omega, th, ...): include it last and only for the declarations
 #include "../../include/AMG.hpp"
+#include "../../include/AMG_gpu_phases.hpp"
+#include "../../include/AMG_gpu_phases_2.hpp"
 
 // ------------------------------------------------------------------------------ containers
 
@@ -289,3 +291,132 @@ SPARSH_KRYLOV_ENTRY(Solver_PBiCG_1, SPARSH_PBICG)
 SPARSH_KRYLOV_ENTRY(Solver_PBiCG_2, SPARSH_PBICG)
 SPARSH_KRYLOV_ENTRY(Solver_PBiCG_3, SPARSH_PBICG)
 SPARSH_KRYLOV_ENTRY(Solver_PBiCG_4, SPARSH_PBICG)
+
+// ------------------------------------------------------------------------------ solver objects
+// AMG_solver / AMG_GPU1_solver / AMG_GPU_solver (include/AMG_phases.hpp, AMG_gpu_phases*.hpp of the
+// reference): user code that drives V-cycles itself, as the reference's own Krylov solvers do
+// (src/AMG_main_solvers.cpp:129-147: setup once, then AMG_solve_jacobi(r, z, 1) per iteration).
+
+AMG_solver::AMG_solver() {}
+
+void AMG_solver::release()
+{
+    if (engine_) sparsh_destroy(static_cast<sparsh_handle>(engine_));
+    engine_ = nullptr;
+    if (Av) {
+        for (int q = 1; q <= l; q++) {  // Av[0] is the caller's object
+            if (Av[q]) {
+                delete[] Av[q]->rowptr;
+                delete[] Av[q]->colindex;
+                delete[] Av[q]->val;
+                delete Av[q];
+            }
+        }
+        delete[] Av;
+        Av = nullptr;
+    }
+    if (Pv) {
+        for (int q = 0; q < l; q++) {
+            if (Pv[q]) {
+                delete[] Pv[q]->rowptr;
+                delete[] Pv[q]->colindex;
+                delete[] Pv[q]->val;
+                delete Pv[q];
+            }
+        }
+        delete[] Pv;
+        Pv = nullptr;
+    }
+    l = 0;
+}
+
+AMG_solver::~AMG_solver() { release(); }  // also tolerates the explicit `S->~AMG_solver()` of the reference
+
+void AMG_solver::AMG_solver_setup_jacobi(sp_matrix_mg &A)
+{
+    release();
+    sparsh_handle h = nullptr;
+    if (sparsh_create_csr(A.nrow, A.ncol, A.rowptr, A.colindex, A.val, &h) != SPARSH_OK) {
+        std::cout << "sparsh: " << sparsh_last_error() << std::endl;
+        return;
+    }
+    sparsh_params p;
+    sparsh_default_params(&p);
+    const int rc = sparsh_setup(h, &p);
+    if (rc != SPARSH_OK) {
+        std::cout << "sparsh: setup failed: " << sparsh_last_error() << std::endl;
+        sparsh_destroy(h);
+        if (rc == SPARSH_ENODEV) std::exit(1);
+        return;
+    }
+    engine_ = h;
+    const int nl = sparsh_num_levels(h);
+    l = nl - 1;
+    Av = new sp_matrix_mg *[nl]();
+    Pv = new sp_matrix_mg *[nl > 1 ? nl - 1 : 1]();
+    Av[0] = &A;
+    for (int q = 0; q < nl; q++) {
+        int nrow = 0, nnz = 0, pn = 0, pnnz = 0;
+        sparsh_level_info(h, q, &nrow, &nnz, &pn, &pnnz);
+        if (q > 0) {
+            Av[q] = new sp_matrix_mg(nrow, nrow, nnz);
+            sparsh_level_csr(h, q, 0, Av[q]->rowptr, Av[q]->colindex, Av[q]->val);
+            Av[q]->sp_matrix_fill_diagonal();
+        }
+        if (q < l) {
+            Pv[q] = new sp_matrix_mg(nrow, pn, pnnz);
+            sparsh_level_csr(h, q, 1, Pv[q]->rowptr, Pv[q]->colindex, Pv[q]->val);
+        }
+    }
+}
+
+void AMG_solver::AMG_solver_setup_SOR(sp_matrix_mg &)
+{
+    std::cerr << "sparsh: AMG_solver_setup_SOR (SOR smoother) is not part of the MI355X build" << std::endl;
+}
+
+void AMG_solver::AMG_solve_jacobi(double *&b, double *&x, int iterations)
+{
+    if (!engine_) {
+        std::cout << "sparsh: AMG_solve_jacobi called before AMG_solver_setup_jacobi" << std::endl;
+        return;
+    }
+    int cycles = 0;
+    if (sparsh_vcycle(static_cast<sparsh_handle>(engine_), b, x, iterations, nullptr, 0, &cycles) != SPARSH_OK)
+        std::cout << "sparsh: " << sparsh_last_error() << std::endl;
+}
+
+void AMG_solver::AMG_solve_SOR(double *&, double *&, int)
+{
+    std::cerr << "sparsh: AMG_solve_SOR (SOR smoother) is not part of the MI355X build; x left unchanged" << std::endl;
+}
+
+void AMG_GPU1_solver::GPU_Allocations() {}
+
+void AMG_GPU1_solver::helper(double *b, double *x, int iterations) { AMG_solve_jacobi(b, x, iterations); }
+
+void AMG_GPU1_solver::AMG_Solve(double *b, double *x, int iterations)
+{
+    if (!engine_) {
+        std::cout << "sparsh: AMG_Solve called before AMG_solver_setup_jacobi" << std::endl;
+        return;
+    }
+    int cycles = 0;
+    if (sparsh_vcycle_dev(static_cast<sparsh_handle>(engine_), b, x, iterations, nullptr, 0, &cycles) != SPARSH_OK)
+        std::cout << "sparsh: " << sparsh_last_error() << std::endl;
+}
+
+void AMG_GPU_solver::GPU_Allocations() {}
+
+void AMG_GPU_solver::AMG_GPU_solve(double *b, double *x, int iterations) { AMG_solve_jacobi(b, x, iterations); }
+
+void AMG_GPU_solver::AMG_GPU_solve_1(double *b, double *x, int iterations)
+{
+    if (!engine_) {
+        std::cout << "sparsh: AMG_GPU_solve_1 called before AMG_solver_setup_jacobi" << std::endl;
+        return;
+    }
+    int cycles = 0;
+    if (sparsh_vcycle_dev(static_cast<sparsh_handle>(engine_), b, x, iterations, nullptr, 0, &cycles) != SPARSH_OK)
+        std::cout << "sparsh: " << sparsh_last_error() << std::endl;
+}

@@ -253,6 +253,14 @@ int sparsh_vcycle(sparsh_handle h, const double *b, double *x, int iterations, d
     return rc;
 }
 
+int sparsh_vcycle_dev(sparsh_handle h, const double *b_dev, double *x_dev, int iterations, double *hist, int hist_cap, int *ncycles)
+{
+    REQUIRE_READY(h);
+    int rc = h->eng->amg_solve_dev(b_dev, x_dev, iterations, hist, hist_cap, ncycles);
+    if (rc != SPARSH_OK) return fail(rc, h->eng->error);
+    return rc;
+}
+
 int sparsh_solve(sparsh_handle h, int method, const double *b, double *x, double *hist, int hist_cap, int *iters)
 {
     REQUIRE_READY(h);

@@ -42,8 +42,10 @@ public:
     {
         if (p.recv.empty() && p.send.empty()) return true;
         if (!ok(ncclGroupStart(), "ncclGroupStart")) return false;
-        for (const HaloSeg &s : p.send)
-            if (!ok(ncclSend(p.sendbuf + s.off, (size_t)s.cnt, ncclDouble, s.peer, comm, st), "ncclSend")) return false;
+        for (const HaloSeg &s : p.send) {
+            const double *src = s.start >= 0 ? vec + s.start : p.sendbuf + s.off;
+            if (!ok(ncclSend(src, (size_t)s.cnt, ncclDouble, s.peer, comm, st), "ncclSend")) return false;
+        }
         for (const HaloSeg &r : p.recv)
             if (!ok(ncclRecv(vec + p.nloc + r.off, (size_t)r.cnt, ncclDouble, r.peer, comm, st), "ncclRecv")) return false;
         return ok(ncclGroupEnd(), "ncclGroupEnd");
@@ -110,6 +112,7 @@ struct ThreadGroup {
     int arrived = 0;
     long generation = 0;
     std::vector<const DevPlan *> plans;
+    std::vector<double *> vecs;
     std::vector<double *> ptrs;
     std::vector<std::vector<double>> host;
     void wait()
@@ -131,6 +134,7 @@ ThreadGroup *thread_group_create(int nranks)
     ThreadGroup *g = new ThreadGroup();
     g->n = nranks;
     g->plans.assign((size_t)nranks, nullptr);
+    g->vecs.assign((size_t)nranks, nullptr);
     g->ptrs.assign((size_t)nranks, nullptr);
     g->host.resize((size_t)nranks);
     return g;
@@ -147,6 +151,7 @@ public:
         // publish my packed send buffer, then pull my halo segments out of the peers' buffers
         (void)hipStreamSynchronize(st);
         g->plans[rank] = &p;
+        g->vecs[rank] = vec;
         g->wait();
         for (const HaloSeg &r : p.recv) {
             const DevPlan *q = g->plans[r.peer];
@@ -158,7 +163,8 @@ public:
                 g->wait();
                 return false;
             }
-            (void)hipMemcpyAsync(vec + p.nloc + r.off, q->sendbuf + src->off, (size_t)r.cnt * sizeof(double), hipMemcpyDeviceToDevice, st);
+            const double *from = src->start >= 0 ? g->vecs[r.peer] + src->start : q->sendbuf + src->off;
+            (void)hipMemcpyAsync(vec + p.nloc + r.off, from, (size_t)r.cnt * sizeof(double), hipMemcpyDeviceToDevice, st);
         }
         (void)hipStreamSynchronize(st);
         g->wait();

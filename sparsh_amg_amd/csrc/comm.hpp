@@ -20,6 +20,7 @@ struct DevPlan {
     int *send_idx = nullptr;   // device, nsend
     double *sendbuf = nullptr; // device, nsend
     std::vector<HaloSeg> recv, send;
+    bool need_pack = false;  // some send segment is not a contiguous run of the vector
     bool empty() const { return nhalo == 0 && nsend == 0; }
 };
 
@@ -27,7 +28,8 @@ class Comm {
 public:
     virtual ~Comm() = default;
     int rank = 0, size = 1;
-    // vec holds nloc own entries followed by room for nhalo received ones; sendbuf is already packed
+    // vec holds nloc own entries followed by room for nhalo received ones; non-contiguous send
+    // segments are already packed into sendbuf, contiguous ones (start >= 0) go out of vec in place
     virtual bool exchange(const DevPlan &p, double *vec, hipStream_t st) = 0;
     // in-place sum over ranks of n doubles in device memory
     virtual bool allreduce_sum(double *dev, int n, hipStream_t st) = 0;

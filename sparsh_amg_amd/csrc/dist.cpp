@@ -106,7 +106,7 @@ LocalOp extract_local(const HostCsr &M, const Partition &rowsP, const Partition 
         const int peer = colsP.owner(remote[q]);
         size_t e = q;
         while (e < remote.size() && colsP.owner(remote[e]) == peer) ++e;
-        L.plan.recv.push_back({peer, (int)q, (int)(e - q)});
+        L.plan.recv.push_back({peer, (int)q, (int)(e - q), -1});
         q = e;
     }
     A.gcol_store = A.col_store;  // global columns, before renumbering
@@ -134,7 +134,9 @@ LocalOp extract_local(const HostCsr &M, const Partition &rowsP, const Partition 
         std::sort(need.begin(), need.end());
         need.erase(std::unique(need.begin(), need.end()), need.end());
         if (need.empty()) continue;
-        L.plan.send.push_back({h, (int)L.plan.send_idx.size(), (int)need.size()});
+        HaloSeg seg{h, (int)L.plan.send_idx.size(), (int)need.size(), -1};
+        if (need.back() - need.front() + 1 == (int)need.size()) seg.start = need.front() - clo;  // contiguous run
+        L.plan.send.push_back(seg);
         for (int c : need) L.plan.send_idx.push_back(c - clo);
     }
     return L;

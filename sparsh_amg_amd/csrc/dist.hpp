@@ -36,6 +36,8 @@ Partition coarse_partition(const HostCsr &R, const Partition &fine);
 
 struct HaloSeg {
     int peer = 0, off = 0, cnt = 0;
+    int start = -1;  // send segments: >= 0 when the entries are the contiguous run [start, start+cnt) of
+                     // the own vector (slab partitions: a whole boundary plane) -- sent in place, no packing
 };
 
 // Exchange plan of one operator: which entries of the input vector this rank must receive

@@ -249,6 +249,8 @@ bool Engine::upload_plan(const HaloPlan &h, DevPlan &d)
     d.nsend = (int)h.send_idx.size();
     d.recv = h.recv;
     d.send = h.send;
+    d.need_pack = false;
+    for (const HaloSeg &sg : d.send) d.need_pack = d.need_pack || sg.start < 0;
     if (d.nsend > 0) {
         d.send_idx = upload(*this, h.send_idx.data(), h.send_idx.size());
         d.sendbuf = static_cast<double *>(dalloc((size_t)d.nsend * 8));
@@ -408,7 +410,7 @@ double Engine::read_hist(int it)
 bool Engine::halo(const DevPlan &p, double *vec)
 {
     if (!dist_) return true;
-    if (p.nsend > 0) launch_pack(p.nsend, p.send_idx, vec, p.sendbuf, st_);
+    if (p.nsend > 0 && p.need_pack) launch_pack(p.nsend, p.send_idx, vec, p.sendbuf, st_);
     if (!comm_->exchange(p, vec, st_)) {
         error = "halo exchange failed: " + comm_->error;
         return false;

@@ -54,7 +54,6 @@ constexpr int kBlock = 256;       // threads per workgroup (4 waves)
 constexpr int kStreamNnz = 2048;  // products staged in LDS per workgroup (16 KiB)
 constexpr int kWaveNnz = 512;     // products staged in LDS per wave (4 KiB) in the wave-granular kernel
 constexpr int kCsrPad = 4;        // zeroed entries appended to col/val so paired loads stay in bounds
-constexpr int kMaxPartials = 1 << 20;
 
 // epilogue selector of the CSR-stream kernel: what happens to the row sum s_i = (A x)_i
 enum CsrOp : int {

@@ -23,6 +23,10 @@ def test_cpp_entry_points_exported():
     out = subprocess.check_output(["nm", "-D", "--defined-only", "-C", os.path.join(LIB_DIR, "libsparsh_amg.so")], text=True)
     for name in ENTRY_POINTS:
         assert re.search(rf"\bT {name}\(", out), name
+    for cls in ("AMG_solver::AMG_solver_setup_jacobi(sp_matrix_mg&)", "AMG_solver::AMG_solve_jacobi(double*&, double*&, int)",
+                "AMG_GPU1_solver::AMG_Solve(double*, double*, int)", "AMG_GPU1_solver::helper(double*, double*, int)",
+                "AMG_GPU_solver::AMG_GPU_solve(double*, double*, int)"):
+        assert cls in out, cls
     for cls in ("sp_matrix::sp_matrix(int, int, int)", "sp_matrix_mg::sp_matrix_fill()", "sp_matrix_mg::sp_matrix_fill_diagonal()",
                 "sp_matrix_mg::~sp_matrix_mg()", "sp_matrix_mg::scale_system(double*&)", "sp_matrix_mg::normalize_matrix()"):
         assert cls in out, cls

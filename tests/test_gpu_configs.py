@@ -60,6 +60,34 @@ def test_cpp_entry_points_on_device(driver, entry, method):
         assert len(re.findall(r"^\d+\t[0-9.e+-]+$", out, re.M)) == len(ho)
 
 
+def test_solver_objects_api(driver, tmp_path):
+    """AMG_solver / AMG_GPU1_solver / AMG_GPU_solver (solver-object layer of the reference API)."""
+    _, mf, rf, (rp, ci, v, b) = driver
+    exe = tmp_path / "solver_objects"
+    cmd = ["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", f"-I{os.path.join(ROOT, 'include')}", "-I/opt/rocm/include",
+           os.path.join(ROOT, "tests", "cpp", "solver_objects.cpp"), "-o", str(exe), f"-L{LIB_DIR}", "-lsparsh_amg", "-L/opt/rocm/lib",
+           "-lamdhip64", f"-Wl,-rpath,{LIB_DIR}", "-L/opt/rocm/lib/llvm/lib", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib/llvm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe), mf, rf], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    out = r.stdout
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET))
+    x = np.zeros(A.nrow)
+    A.vcycle(b, x, iterations=3)
+    lv = re.search(r"LEVELS (\d+)((?: \d+:\d+)+) P0 (\d+)x(\d+)", out)
+    assert lv and int(lv.group(1)) == A.nlevels
+    sizes = [tuple(int(t) for t in s.split(":")) for s in lv.group(2).split()]
+    assert sizes == [(A.level_info(l)["nrow"], A.level_info(l)["nnz"]) for l in range(A.nlevels)]
+    assert (int(lv.group(3)), int(lv.group(4))) == (A.nrow, A.level_info(0)["p_ncol"])
+    for tag in ("HOST3", "HELPER3", "DEVICE3"):
+        m = re.search(tag + r" (\S+) (\S+)", out)
+        assert m, out[-1500:]
+        assert float(m.group(1)) == x[0] and abs(float(m.group(2)) - np.linalg.norm(x)) <= 1e-12 * np.linalg.norm(x)
+    m = re.search(r"CI_SOLVE (\S+)", out)
+    assert m and float(m.group(1)) <= 1.001e-8
+
+
 def test_sor_entry_point_is_a_stub(driver):
     exe, mf, rf, _ = driver
     r = subprocess.run([exe, mf, rf, "sor"], capture_output=True, text=True, timeout=120)
