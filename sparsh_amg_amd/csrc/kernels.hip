@@ -554,17 +554,21 @@ int launch_csr_op(const DevCsr &A, const CsrArgs &a, bool finest, hipStream_t st
     bool nt = c.nt;
     int remap = c.remap;
     if (c.auto_policy) {
-        // measured on MI355X (profiles/r01_remap_sweep.txt): operators far beyond the 256 MiB
-        // Infinity Cache stream best with non-temporal loads and all XCDs sweeping one
-        // neighbourhood (groups of 16 row blocks); operators a few times the cache size prefer
-        // one contiguous eighth per XCD; cache-resident operators additionally drop the nt hint.
-        const size_t bytes = (size_t)A.nnz * 12 + (size_t)A.nrow * 36;
-        if (bytes > (900u << 20)) {
+        // measured on MI355X (profiles/r01_remap_sweep.txt, r01_remap_sweep_sdia.txt): what decides is
+        // whether one sweep's working set -- the bytes of the layout actually used plus the
+        // vectors -- stays in the 256 MiB Infinity Cache between consecutive sweeps.  If it does:
+        // default cache policy, one contiguous eighth of the rows per XCD.  If not: non-temporal
+        // matrix stream and all XCDs sweeping one neighbourhood (groups of 16 row blocks).
+        size_t bytes;
+        if (c.kind == 3 && A.sd_val)
+            bytes = (size_t)A.sd_slots * 64 * 8 + (size_t)A.nrow * 24;
+        else if (c.kind >= 2 && A.sell_val)
+            bytes = (size_t)A.sell_entries * 12 + (size_t)A.nrow * 28;
+        else
+            bytes = (size_t)A.nnz * 12 + (size_t)A.nrow * 36;
+        if (bytes > (240u << 20)) {
             nt = true;
             remap = 16;
-        } else if (bytes > (200u << 20)) {
-            nt = true;
-            remap = 1;
         } else {
             nt = false;
             remap = 1;
