@@ -18,6 +18,7 @@ from __future__ import annotations
 import argparse
 import ctypes
 import json
+import threading
 import os
 import sys
 import time
@@ -279,7 +280,7 @@ def main():
             "first_residuals_match_gpu": bool(np.allclose(ho, hist[: len(ho)], rtol=1e-6)) if args.warmup + args.steps >= len(ho) else None,
         }
 
-    if rank == 0:
+    if True:
         line = {
             "metric": "AMG-PCG solve iterations/sec (7-pt 3D Poisson, fp64) + HBM GB/s",
             "value": round(its_per_s, 3),
@@ -313,8 +314,71 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+
+    printed = threading.Event()
+
+    def emit():
+        if rank == 0 and not printed.is_set():
+            printed.set()
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+
+    # ---- multi-GPU phase B: the same K timed steps with the halo exchange overlapped with the
+    # interior slices (second stream).  This schedule has only been exercised with the in-process
+    # test transport, never on xGMI, so it runs under a watchdog: if it hangs, fails the parity
+    # check against phase A, or is not faster, the phase-A record above is the one that is printed.
+    force_b = os.environ.get("SPARSH_BENCH_FORCE_PHASE_B", "0") == "1"  # exercise this code path on one GPU
+    if mode == "partitioned" and (world > 1 or force_b) and os.environ.get("SPARSH_BENCH_TRY_OVERLAP", "1") == "1":
+        def bail():
+            log("overlap phase timed out: reporting the non-overlapped measurement")
+            emit()
+            os._exit(0)
+
+        dog = threading.Timer(float(os.environ.get("SPARSH_BENCH_OVERLAP_TIMEOUT", "90")), bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            import torch
+
+            log("phase B: overlapped halo exchange")
+            A.set_overlap(True)
+            A.set_stopping(0.0, 100000, 1 << 30)
+            A.h2d(xd, np.zeros(nloc))
+            A.krylov_init_dev("pcg", bd, xd)
+            if args.warmup > 0:
+                A.krylov_step_dev(args.warmup)
+            if not no_profile:
+                A.profile(True)  # same per-launch event overhead as phase A
+            barrier()
+            tb0 = time.perf_counter()
+            done_b, _ = A.krylov_step_dev(args.steps)
+            barrier()
+            el_b = time.perf_counter() - tb0
+            if not no_profile:
+                A.profile(False)
+            hist_b = A.krylov_history()
+            m = min(len(hist_b), len(hist))
+            good = int(done_b == args.steps and m > 0 and np.all(np.isfinite(hist_b)) and
+                       float(np.max(np.abs(hist_b[:m] - hist[:m]) / hist[:m])) < 1e-6)
+            if dist is not None:
+                t = torch.tensor([el_b, -float(good)], device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)  # slowest rank's time; any rank's failure
+                el_b, good = float(t[0].item()), int(-t[1].item()) == 1
+            good = bool(good)
+            line["config"]["overlap_phase"] = {"ms_per_step": round(el_b / args.steps * 1e3, 4), "history_matches_phase_a": good,
+                                               "adopted": bool(good and el_b < elapsed)}
+            line["config"]["non_overlapped_ms_per_step"] = line["ms_per_step"]
+            if good and el_b < elapsed:
+                line["value"] = round(args.steps / el_b, 3)
+                line["ms_per_step"] = round(el_b / args.steps * 1e3, 4)
+                line["config"]["solve_GBps"] = round(it_bytes * args.steps / el_b / 1e9, 1)
+                line["config"]["solve_frac_of_8TBps"] = round(it_bytes * args.steps / el_b / 1e9 / HBM_PEAK_GBS, 4)
+                line["config"]["parallelism"] += "; halo exchange overlapped with the interior slices on a second stream"
+        except Exception as e:  # noqa: BLE001
+            log(f"overlap phase failed: {e!r}")
+            line["config"]["overlap_phase"] = {"error": repr(e), "adopted": False}
+        dog.cancel()
+    emit()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -200,6 +200,10 @@ int sparsh_set_device(int device); /* make `device` current for this thread (cal
 int sparsh_comm_unique_id(char id128[128]);
 int sparsh_comm_init_rccl(sparsh_handle h, const char id128[128], int rank, int nranks);
 int sparsh_local_range(sparsh_handle h, int level, int *lo, int *hi, int *replicated);
+/* Overlap the halo exchange with computation (default off): the exchange is issued on a second
+ * stream while the 64-row slices that reference no halo column are processed; the boundary slices
+ * follow once the halo has landed.  Same arithmetic, same results.  May be toggled between solves. */
+int sparsh_set_overlap(sparsh_handle h, int enable);
 
 /* In-process transport for tests: nranks handles driven by nranks host threads on one GPU. */
 int sparsh_comm_group_create(int nranks, void **group);

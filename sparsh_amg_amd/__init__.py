@@ -94,6 +94,7 @@ def _load():
         "sparsh_comm_unique_id": (C.c_int, [C.c_char_p]),
         "sparsh_comm_init_rccl": (C.c_int, [H, C.c_char_p, C.c_int, C.c_int]),
         "sparsh_local_range": (C.c_int, [H, C.c_int, c_int_p, c_int_p, c_int_p]),
+        "sparsh_set_overlap": (C.c_int, [H, C.c_int]),
         "sparsh_comm_group_create": (C.c_int, [C.c_int, P(C.c_void_p)]),
         "sparsh_comm_group_destroy": (None, [C.c_void_p]),
         "sparsh_comm_init_group": (C.c_int, [H, C.c_void_p, C.c_int]),
@@ -284,6 +285,10 @@ class sp_matrix_mg:
     def comm_init_group(self, group, rank: int):
         """Install the in-process test transport (call before setup)."""
         _check(lib.sparsh_comm_init_group(self._h, group, rank))
+
+    def set_overlap(self, enable=True):
+        """Multi-GPU: overlap halo exchange with the interior slices (same results)."""
+        _check(lib.sparsh_set_overlap(self._h, 1 if enable else 0))
 
     def local_range(self, level=0):
         lo, hi, rep = C.c_int(), C.c_int(), C.c_int()

@@ -327,6 +327,13 @@ int sparsh_comm_init_group(sparsh_handle h, void *group, int rank)
     return SPARSH_OK;
 }
 
+int sparsh_set_overlap(sparsh_handle h, int enable)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    h->eng->set_overlap(enable != 0);
+    return SPARSH_OK;
+}
+
 int sparsh_local_range(sparsh_handle h, int level, int *lo, int *hi, int *replicated)
 {
     REQUIRE_READY(h);

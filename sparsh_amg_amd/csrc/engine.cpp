@@ -60,6 +60,9 @@ Engine::~Engine()
     for (auto e : prof.ev) (void)hipEventDestroy(e);
     for (void *p : allocs_) (void)hipFree(p);
     if (pinned_) (void)hipHostFree(pinned_);
+    if (ev_ready_) (void)hipEventDestroy(ev_ready_);
+    if (ev_halo_) (void)hipEventDestroy(ev_halo_);
+    if (st2_) (void)hipStreamDestroy(st2_);
     if (st_) (void)hipStreamDestroy(st_);
 }
 
@@ -329,6 +332,20 @@ int Engine::setup(const sparsh_params &p)
             d.n = pl.hi(me) - pl.lo(me);
             LocalOp la = extract_local(h.A, pl, pl, me);
             if (!upload_csr(*this, la.M, d.A, true) || !upload_plan(la.plan, d.planA)) return SPARSH_ENODEV;
+            {  // slices whose rows reference no halo column can run while the exchange is in flight
+                const int nloc = la.plan.nloc, nsl = (la.M.nrow + 63) / 64;
+                std::vector<int> il, bl;
+                for (int sl = 0; sl < nsl; ++sl) {
+                    bool touches = false;
+                    const int r1 = std::min(la.M.nrow, (sl + 1) * 64);
+                    for (int j = la.M.rowptr[sl * 64]; j < la.M.rowptr[r1] && !touches; ++j) touches = la.M.col[j] >= nloc;
+                    (touches ? bl : il).push_back(sl);
+                }
+                d.A.nint = (int)il.size();
+                d.A.nbnd = (int)bl.size();
+                if (!il.empty()) d.A.int_list = upload(*this, il.data(), il.size());
+                if (!bl.empty()) d.A.bnd_list = upload(*this, bl.data(), bl.size());
+            }
             d.diag = upload(*this, h.diag.data() + pl.lo(me), (size_t)d.n);
             // P_l: my fine rows, columns in the coarse space (replicated coarse space: global columns)
             LocalOp lp = extract_local(h.P, pl, parts_[l + 1], me);
@@ -382,6 +399,12 @@ int Engine::setup(const sparsh_params &p)
         (void)hipMemsetAsync(w, 0, wcap * 8, st_);
         work_.push_back(w);
     }
+    if (dist_ && !st2_) {
+        if (!check(hipStreamCreateWithFlags(&st2_, hipStreamNonBlocking), "hipStreamCreate") ||
+            !check(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming), "hipEventCreate") ||
+            !check(hipEventCreateWithFlags(&ev_halo_, hipEventDisableTiming), "hipEventCreate"))
+            return SPARSH_ENODEV;
+    }
     if (!check(hipStreamSynchronize(st_), "setup sync")) return SPARSH_ENODEV;
     if (!comm_->barrier(st_)) {
         error = "comm barrier after setup failed: " + comm_->error;
@@ -418,6 +441,35 @@ bool Engine::halo(const DevPlan &p, double *vec)
     return true;
 }
 
+int Engine::apply_A(DevLevel &L, CsrOp op, CsrArgs a)
+{
+    double *xin = const_cast<double *>(a.x);
+    const KernelConfig &kc = kernel_config();
+    const bool sliced = (kc.kind == 3 && L.A.sd_val) || (kc.kind >= 2 && L.A.sell_val);
+    if (!(dist_ && overlap_ && !L.replicated && sliced && L.A.nint > 0 && L.A.nbnd > 0 && st2_)) {
+        halo(L.planA, xin);
+        return launch_csr(L.A, op, a, L.fine, st_);
+    }
+    // overlap: [st2] wait until x is final -> pack + exchange ; [st] interior slices meanwhile ;
+    //          [st] wait for the halo -> boundary slices
+    (void)hipEventRecord(ev_ready_, st_);
+    (void)hipStreamWaitEvent(st2_, ev_ready_, 0);
+    const DevPlan &p = L.planA;
+    if (p.nsend > 0 && p.need_pack) launch_pack(p.nsend, p.send_idx, xin, p.sendbuf, st2_);
+    if (!comm_->exchange(p, xin, st2_)) error = "halo exchange failed: " + comm_->error;
+    (void)hipEventRecord(ev_halo_, st2_);
+    a.slice_list = L.A.int_list;
+    a.nlist = L.A.nint;
+    a.partial_off = 0;
+    const int n1 = launch_csr(L.A, op, a, L.fine, st_);
+    (void)hipStreamWaitEvent(st_, ev_halo_, 0);
+    a.slice_list = L.A.bnd_list;
+    a.nlist = L.A.nbnd;
+    a.partial_off = n1;
+    const int n2 = launch_csr(L.A, op, a, L.fine, st_);
+    return n1 + n2;
+}
+
 // Reduce per-workgroup partials and update the device scalars; across ranks the local sums are
 // all-reduced in between (one 16-byte ncclAllReduce).
 void Engine::finalize(Fin code, const double *p0, const double *p1, int nblk, int slot, double *hist, int it)
@@ -437,31 +489,28 @@ void Engine::finalize(Fin code, const double *p0, const double *p1, int nblk, in
 
 void Engine::op_spmv(int l, const double *x, double *y)
 {
-    halo(lev_[l].planA, const_cast<double *>(x));
     CsrArgs a;
     a.x = x;
     a.y = y;
-    launch_csr(lev_[l].A, OP_SPMV, a, lev_[l].fine, st_);
+    apply_A(lev_[l], OP_SPMV, a);
 }
 
 void Engine::op_residual(int l, const double *b, const double *x, double *r)
 {
-    halo(lev_[l].planA, const_cast<double *>(x));
     CsrArgs a;
     a.x = x;
     a.b = b;
     a.y = r;
-    launch_csr(lev_[l].A, OP_RESID, a, lev_[l].fine, st_);
+    apply_A(lev_[l], OP_RESID, a);
 }
 
 double Engine::op_resnorm(int l, const double *b, const double *x)
 {
-    halo(lev_[l].planA, const_cast<double *>(x));
     CsrArgs a;
     a.x = x;
     a.b = b;
     a.partial = part0_;
-    const int np = launch_csr(lev_[l].A, OP_RESNORM, a, lev_[l].fine, st_);
+    const int np = apply_A(lev_[l], OP_RESNORM, a);
     finalize(FIN_SQRT, part0_, nullptr, np, S_RES, nullptr, 0);
     return read_scalar(S_RES);
 }
@@ -515,7 +564,6 @@ void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, doubl
     const bool timed = prof.enabled && &L == &lev_[0];
     for (; k < sweeps; ++k) {
         const bool last = (k == sweeps - 1);
-        halo(L.planA, L.x);
         CsrArgs a;
         a.x = L.x;
         a.b = b;
@@ -530,7 +578,7 @@ void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, doubl
         }
         const bool rec = timed && prof.used + 2 <= prof.ev.size();
         if (rec) (void)hipEventRecord(prof.ev[prof.used++], st_);
-        const int np = launch_csr(L.A, op, a, L.fine, st_);
+        const int np = apply_A(L, op, a);
         if (op == OP_JACOBI_DOT) *dot_nblk = np;
         if (rec) (void)hipEventRecord(prof.ev[prof.used++], st_);
         std::swap(L.x, L.x2);
@@ -657,12 +705,11 @@ void Engine::pcg_body(bool precond, int slot)
     double *r = work_[0], *p = work_[1], *Ap = work_[2];
     double *x = ks_.x;
     int nb = 0;
-    halo(lev_[0].planA, p);
     CsrArgs a;
     a.x = p;
     a.y = Ap;
     a.partial = part0_;
-    const int np = launch_csr(lev_[0].A, OP_SPMV_DOT, a, lev_[0].fine, st_);  // Ap = A p ; p.Ap
+    const int np = apply_A(lev_[0], OP_SPMV_DOT, a);  // Ap = A p ; p.Ap
     finalize(precond ? FIN_PCG_ALPHA : FIN_CG_ALPHA, part0_, nullptr, np, 0, nullptr, 0);
     launch_cg_update(n, scal_, p, Ap, x, r, part0_, &nb, st_);  // x += alpha p ; r -= alpha Ap ; r.r
     if (precond) {

@@ -70,6 +70,8 @@ public:
     int local_n0() const { return lev_.empty() ? A0_.nrow : lev_[0].n; }
     // multi-GPU: install the transport before setup(); the engine owns it
     void set_comm(std::unique_ptr<Comm> c) { comm_ = std::move(c); }
+    void set_overlap(bool on) { overlap_ = on; }
+    bool overlap() const { return overlap_; }
     Comm *comm() const { return comm_.get(); }
     bool distributed() const { return dist_; }
     const Partition &partition(int l) const { return parts_[l]; }
@@ -119,6 +121,10 @@ private:
     void vcycle(const double *b0, bool x0_zero, double *dot_partial, int *dot_nblk);
     void smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, double *dot_partial, int *dot_nblk);
     bool halo(const DevPlan &p, double *vec);  // pack + exchange (no-op on one GPU)
+    // A_l-type operator on level L: exchanges the halo of a.x, then launches; with overlap enabled the
+    // exchange runs on a second stream while the slices that touch no halo column are processed.
+    // Returns the number of reduction partials written.
+    int apply_A(DevLevel &L, CsrOp op, CsrArgs a);
     void finalize(Fin code, const double *p0, const double *p1, int nblk, int slot, double *hist, int it);
     bool upload_plan(const HaloPlan &h, DevPlan &d);
     double read_scalar(int slot);
@@ -135,6 +141,9 @@ private:
     Partition gather_part_;         // share of the first replicated level each rank restricts, then all-gathers
     int repl_level_ = 0;            // first replicated level (0: nothing is partitioned)
     bool dist_ = false;
+    bool overlap_ = false;          // multi-GPU: overlap halo exchange with interior slices
+    hipStream_t st2_ = nullptr;     // exchange stream of the overlap path
+    hipEvent_t ev_ready_ = nullptr, ev_halo_ = nullptr;
     KrylovState ks_;
     HostCsr A0_;
     HostHierarchy H_;

@@ -396,9 +396,11 @@ __global__ __launch_bounds__(kBlock) void sell_kernel(int nrow, int nslice, int 
     const int gid = remap ? xcd_remap(blockIdx.x, ngroups, remap) : blockIdx.x;
     if (gid >= ngroups) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int sl = gid * (kBlock / 64) + w;
+    const int idx = gid * (kBlock / 64) + w;
+    const int nwork = a.slice_list ? a.nlist : nslice;
     double acc = 0.0;
-    if (sl < nslice) {
+    if (idx < nwork) {
+        const int sl = a.slice_list ? __builtin_amdgcn_readfirstlane(a.slice_list[idx]) : idx;
         const int row = sl * 64 + lane;
         const bool has_row = row < nrow;
         const int base = __builtin_amdgcn_readfirstlane(slice_ptr[sl]);
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(kBlock) void sell_kernel(int nrow, int nslice, int 
     }
     if constexpr (op_reduces(OP)) {
         const double t = block_sum(acc, red);
-        if (threadIdx.x == 0) a.partial[gid] = t;
+        if (threadIdx.x == 0) a.partial[a.partial_off + gid] = t;
     }
 }
 
@@ -477,9 +479,11 @@ __global__ __launch_bounds__(kBlock) void sdia_kernel(int nrow, int nslice, int 
     const int gid = remap ? xcd_remap(blockIdx.x, ngroups, remap) : blockIdx.x;
     if (gid >= ngroups) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int sl = gid * (kBlock / 64) + w;
+    const int idx = gid * (kBlock / 64) + w;
+    const int nwork = a.slice_list ? a.nlist : nslice;
     double acc = 0.0;
-    if (sl < nslice) {
+    if (idx < nwork) {
+        const int sl = a.slice_list ? __builtin_amdgcn_readfirstlane(a.slice_list[idx]) : idx;
         int row = sl * 64 + lane;
         const bool has_row = row < nrow;
         if (!has_row) row = nrow - 1;  // tail lanes of the last slice: masks are clear, keep addresses valid
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void sdia_kernel(int nrow, int nslice, int 
     }
     if constexpr (op_reduces(OP)) {
         const double t = block_sum(acc, red);
-        if (threadIdx.x == 0) a.partial[gid] = t;
+        if (threadIdx.x == 0) a.partial[a.partial_off + gid] = t;
     }
 }
 
@@ -503,7 +507,7 @@ int launch_csr_tagged(const DevCsr &A, const CsrArgs &a, bool nt, int remap, hip
 {
     const KernelConfig &c = g_cfg;
     if (c.kind == 3 && A.sd_val) {
-        const int ngroups = (A.nslice + 3) / 4;
+        const int ngroups = ((a.slice_list ? a.nlist : A.nslice) + 3) / 4;
         if (ngroups <= 0) return 0;
         const int grid = remap_grid(ngroups, remap);
         if (nt)
@@ -513,7 +517,7 @@ int launch_csr_tagged(const DevCsr &A, const CsrArgs &a, bool nt, int remap, hip
         return ngroups;
     }
     if (c.kind >= 2 && A.sell_val) {
-        const int ngroups = (A.nslice + 3) / 4;
+        const int ngroups = ((a.slice_list ? a.nlist : A.nslice) + 3) / 4;
         if (ngroups <= 0) return 0;
         const int grid = remap_grid(ngroups, remap);
         if (nt)

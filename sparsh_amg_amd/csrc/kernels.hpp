@@ -37,6 +37,9 @@ struct DevCsr {
     unsigned long long *sd_mask = nullptr;  // per slot: lanes (rows of the slice) that hold an entry
     double *sd_val = nullptr;           // per slot: 64 values, lane-major
     long sd_slots = 0;
+    // rank-local blocks: slices whose rows touch no halo column (interior) / some (boundary)
+    int *int_list = nullptr, *bnd_list = nullptr;
+    int nint = 0, nbnd = 0;
 };
 
 // run-time choice of the SpMV-type kernel family (A/B measurements; defaults = the fastest measured)
@@ -73,6 +76,11 @@ struct CsrArgs {
     double *y = nullptr;         // output
     double omega = 0.0;
     double *partial = nullptr;   // per-block partial sums (reductions), size >= nblk
+    // optional subset launch of the sliced kernels (multi-GPU overlap): process only the slices
+    // listed, write reduction partials from index partial_off on
+    const int *slice_list = nullptr;
+    int nlist = 0;
+    int partial_off = 0;
 };
 
 // host-side builder of the row-block schedule (returns number of blocks; out sized nrow+1 max)
