@@ -222,6 +222,20 @@ def test_golden_histories(golden):
     assert abs(np.linalg.norm(x) - g["pcg"]["xnorm"]) <= 1e-9 * g["pcg"]["xnorm"]
 
 
+def test_beck_golden(golden):
+    """Device path with Beck coarsening vs the reference's own output."""
+    rp, ci, v = problems.poisson3d(40)
+    A, _ = _mk(rp, ci, v, coarsening=1)
+    g = golden["poisson3d_40"]["beck"]
+    assert [A.level_info(l)["nrow"] for l in range(A.nlevels)] == g["levels_nrow"]
+    assert [A.level_info(l)["nnz"] for l in range(A.nlevels)] == g["levels_nnz_stored"]
+    x = np.zeros(A.nrow)
+    h, rc = A.solve("amg", np.ones(A.nrow), x)
+    assert rc == 0 and len(h) == g["amg"]["cycles"]
+    assert abs(h[0] - g["amg"]["hist_head"][0]) <= 1e-10 * h[0]
+    assert abs(h[-1] - g["amg"]["last"]) <= 1e-3 * h[-1]
+
+
 def test_beck_coarsening():
     rp, ci, v = problems.poisson3d(30)
     A, O = _mk(rp, ci, v, coarsening=1)
