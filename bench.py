@@ -292,7 +292,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if mode != "replicas" else "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64" if not prm.precond_fp32 else "f64 Krylov loop + f32 preconditioner hierarchy (opt-in mode, not the parity path)",
             "data": "synthetic",
             "config": {
                 "workload": f"7-pt 3D Poisson CSR {args.grid}^3 = {n} rows, {nnz} nnz, fp64/int32, AMG-preconditioned CG "

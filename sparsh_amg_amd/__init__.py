@@ -56,6 +56,7 @@ class Params(C.Structure):
         ("check_every", C.c_int),
         ("use_graph", C.c_int),
         ("replicate_rows", C.c_int),
+        ("precond_fp32", C.c_int),
     ]
 
 

@@ -111,6 +111,7 @@ void sparsh_default_params(sparsh_params *p)
     p->check_every = 1;
     p->use_graph = env_int("SPARSH_GRAPH", 0);
     p->replicate_rows = env_int("SPARSH_REPLICATE_ROWS", 1500000);
+    p->precond_fp32 = env_int("SPARSH_PRECOND_FP32", 0);
 }
 
 int sparsh_create_csr(int nrow, int ncol, const int *rowptr, const int *colindex, const double *val, sparsh_handle *out)

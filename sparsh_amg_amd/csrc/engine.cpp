@@ -399,6 +399,8 @@ int Engine::setup(const sparsh_params &p)
         (void)hipMemsetAsync(w, 0, wcap * 8, st_);
         work_.push_back(w);
     }
+    f32_ready_ = false;
+    if (p.precond_fp32 && !setup_f32()) return SPARSH_EINVAL;
     if (dist_ && !st2_) {
         if (!check(hipStreamCreateWithFlags(&st2_, hipStreamNonBlocking), "hipStreamCreate") ||
             !check(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming), "hipEventCreate") ||
@@ -412,6 +414,95 @@ int Engine::setup(const sparsh_params &p)
     }
     ready_ = true;
     return SPARSH_OK;
+}
+
+// Float copy of the hierarchy for the opt-in fp32 preconditioner (values converted on the device).
+bool Engine::setup_f32()
+{
+    const int nl = (int)lev_.size();
+    if (dist_) {
+        error = "precond_fp32 is implemented for one GPU";
+        return false;
+    }
+    if (nl < 2) return true;  // single level: the "V-cycle" is the direct solve, nothing to gain
+    // the float mirror exists for the sliced-diagonal layout; small coarse levels without it run a
+    // simple per-row fallback, but a large level without it would make the mode pointless
+    for (int l = 0; l + 1 < nl; ++l)
+        if (!lev_[l].A.sd_val && lev_[l].n > 100000) {
+            error = "precond_fp32 needs the sliced-diagonal layout on the large levels (level " + std::to_string(l) + " does not qualify)";
+            return false;
+        }
+    f32_.assign((size_t)nl, F32Level());
+    for (int l = 0; l < nl; ++l) {
+        DevLevel &d = lev_[l];
+        F32Level &f = f32_[l];
+        const size_t n = (size_t)d.n;
+        f.x = static_cast<float *>(dalloc(n * 4));
+        f.b = static_cast<float *>(dalloc(n * 4));
+        if (!f.x || !f.b) return false;
+        if (l + 1 < nl) {
+            f.x2 = static_cast<float *>(dalloc(n * 4));
+            f.r = static_cast<float *>(dalloc(n * 4));
+            f.diag = static_cast<float *>(dalloc(n * 4));
+            if (!f.x2 || !f.r || !f.diag) return false;
+            launch_cvt_d2f((long)n, d.diag, f.diag, st_);
+            if (d.A.sd_val) {
+                f.A.nrow = d.n;
+                f.A.nslice = d.A.nslice;
+                f.A.sd_ptr = d.A.sd_ptr;
+                f.A.sd_off = d.A.sd_off;
+                f.A.sd_mask = d.A.sd_mask;
+                f.A.slots = d.A.sd_slots;
+                f.A.val = static_cast<float *>(dalloc((size_t)d.A.sd_slots * 64 * 4));
+                if (!f.A.val) return false;
+                launch_cvt_d2f((long)d.A.sd_slots * 64, d.A.sd_val, f.A.val, st_);
+            }
+        }
+    }
+    coarse_inv_f32_ = static_cast<float *>(dalloc((size_t)nL_ * nL_ * 4));
+    if (!coarse_inv_f32_) return false;
+    launch_cvt_d2f((long)nL_ * nL_, coarse_inv_, coarse_inv_f32_, st_);
+    f32_ready_ = true;
+    return true;
+}
+
+void Engine::vcycle_f32(const double *r64, double *z64, double *partial, int *nblk)
+{
+    const int last = (int)lev_.size() - 1;
+    const int nu = prm_.sweeps;
+    const float w = (float)prm_.omega;
+    launch_cvt_d2f((long)lev_[0].n, r64, f32_[0].b, st_);
+    auto apply = [&](int l, CsrOp op, const float *x, float *y) {
+        F32Level &f = f32_[l];
+        if (f.A.val)
+            launch_sdia_f32(f.A, op, x, f.b, y, w, st_);
+        else
+            launch_csr_f32(lev_[l].A, op, f.diag, x, f.b, y, w, st_);
+    };
+    auto sweeps = [&](int l, int count) {
+        F32Level &f = f32_[l];
+        for (int k = 0; k < count; ++k) {
+            apply(l, OP_JACOBI, f.x, f.x2);
+            std::swap(f.x, f.x2);
+        }
+    };
+    for (int l = 0; l < last; ++l) {
+        F32Level &f = f32_[l];
+        launch_jacobi_zero_f32(lev_[l].n, f.b, f.diag, w, f.x, st_);
+        sweeps(l, nu - 1);
+        apply(l, OP_RESID, f.x, f.r);
+        launch_restrict_f32(lev_[l + 1].n, lev_[l].R.rowptr, lev_[l].R.col, lev_[l].R.val, f.r, f32_[l + 1].b, st_);
+    }
+    launch_gemv_f32(nL_, coarse_inv_f32_, f32_[last].b, f32_[last].x, st_);
+    for (int l = last; l > 0; --l) {
+        DevLevel &F = lev_[l - 1];
+        if (F.P_is_aggregation)
+            launch_prolong_agg_f32(F.n, F.P.col, f32_[l].x, f32_[l - 1].x, st_);
+        else
+            launch_prolong_csr_f32(F.n, F.P.rowptr, F.P.col, F.P.val, f32_[l].x, f32_[l - 1].x, st_);
+        sweeps(l - 1, nu);
+    }
+    launch_cvt_f2d_dot(lev_[0].n, f32_[0].x, r64, z64, partial, nblk, st_);
 }
 
 double Engine::read_scalar(int slot)
@@ -685,7 +776,11 @@ int Engine::pcg_init(const double *b, double *x, bool precond)
     if (!precond) finalize(FIN_STORE, part0_, nullptr, nb, S_RR, nullptr, 0);
     finalize(FIN_SQRT, part0_, nullptr, nb, S_RES, nullptr, 0);
     ks_.r1 = read_scalar(S_RES);
-    if (precond) {
+    if (precond && f32_ready_) {
+        vcycle_f32(r, work_[4], part0_, &nb);  // z0 = V32(r0)
+        finalize(FIN_STORE, part0_, nullptr, nb, S_RZ, nullptr, 0);
+        launch_copy(n, work_[4], p, st_);
+    } else if (precond) {
         vcycle(r, true, part0_, &nb);  // z0 = V(r0), zero initial guess
         finalize(FIN_STORE, part0_, nullptr, nb, S_RZ, nullptr, 0);
         launch_copy(n, lev_[0].x, p, st_);
@@ -712,7 +807,12 @@ void Engine::pcg_body(bool precond, int slot)
     const int np = apply_A(lev_[0], OP_SPMV_DOT, a);  // Ap = A p ; p.Ap
     finalize(precond ? FIN_PCG_ALPHA : FIN_CG_ALPHA, part0_, nullptr, np, 0, nullptr, 0);
     launch_cg_update(n, scal_, p, Ap, x, r, part0_, &nb, st_);  // x += alpha p ; r -= alpha Ap ; r.r
-    if (precond) {
+    if (precond && f32_ready_) {
+        finalize(FIN_SQRT, part0_, nullptr, nb, S_RES, hist_dev_, slot);
+        vcycle_f32(r, work_[4], part0_, &nb);  // float hierarchy, fp64 in/out, fused z0.r0
+        finalize(FIN_PCG_BETA, part0_, nullptr, nb, 0, nullptr, 0);
+        launch_p_update(n, scal_, work_[4], p, st_);
+    } else if (precond) {
         finalize(FIN_SQRT, part0_, nullptr, nb, S_RES, hist_dev_, slot);
         vcycle(r, true, part0_, &nb);  // z0 = 0 ; z0 = V(r0) ; fused z0.r0
         finalize(FIN_PCG_BETA, part0_, nullptr, nb, 0, nullptr, 0);

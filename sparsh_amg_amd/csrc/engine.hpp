@@ -38,6 +38,12 @@ struct KrylovState {
     double r1 = 0.0;
 };
 
+// float mirror of one level for the opt-in fp32 preconditioner
+struct F32Level {
+    SdiaF32 A;
+    float *diag = nullptr, *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr;
+};
+
 struct GraphState {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -74,6 +80,7 @@ public:
     bool overlap() const { return overlap_; }
     Comm *comm() const { return comm_.get(); }
     bool distributed() const { return dist_; }
+    bool precond_fp32_active() const { return f32_ready_; }
     const Partition &partition(int l) const { return parts_[l]; }
     void set_stopping(double tol, int max_iter, int check_every)
     {
@@ -130,6 +137,9 @@ private:
     double read_scalar(int slot);
     double read_hist(int it);
 
+    bool setup_f32();
+    // V(nu,nu) cycle on the float hierarchy from a zero guess: z64 = V32(r64), partial sums of z.r
+    void vcycle_f32(const double *r64, double *z64, double *partial, int *nblk);
     void pcg_body(bool precond, int slot);
     bool capture_graph(bool precond);
     void drop_graph();
@@ -144,6 +154,9 @@ private:
     bool overlap_ = false;          // multi-GPU: overlap halo exchange with interior slices
     hipStream_t st2_ = nullptr;     // exchange stream of the overlap path
     hipEvent_t ev_ready_ = nullptr, ev_halo_ = nullptr;
+    std::vector<F32Level> f32_;
+    float *coarse_inv_f32_ = nullptr;
+    bool f32_ready_ = false;
     KrylovState ks_;
     HostCsr A0_;
     HostHierarchy H_;

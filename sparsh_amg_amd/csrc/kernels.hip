@@ -500,6 +500,154 @@ __global__ __launch_bounds__(kBlock) void sdia_kernel(int nrow, int nslice, int 
     }
 }
 
+// ------------------------------------------------------------------ fp32 preconditioner kernels
+// Same sliced-diagonal structure with float values and float vectors: 4 B per stored entry and
+// 12 B per row for a fused sweep.  Used only inside the (opt-in) fp32 V-cycle; the fp64 parity
+// path never touches them.
+template <int L>
+__device__ __forceinline__ float sdia32_chunk(const int *__restrict__ off, const unsigned long long *__restrict__ mask,
+                                              const float *__restrict__ vp, const float *__restrict__ x, int d0, int row, int lane,
+                                              float &dv, float sum)
+{
+    float v[L], xv[L];
+    bool on[L];
+    int oo[L];
+#pragma unroll
+    for (int u = 0; u < L; ++u) {
+        const int o = __builtin_amdgcn_readfirstlane(off[d0 + u]);
+        oo[u] = o;
+        const unsigned long long m = mask[d0 + u];
+        on[u] = (m >> lane) & 1ull;
+        v[u] = vp[(size_t)(d0 + u) * 64];
+        xv[u] = x[on[u] ? row + o : row];
+    }
+#pragma unroll
+    for (int u = 0; u < L; ++u) {
+        const float t = v[u] * xv[u];
+        sum = on[u] ? sum + t : sum;
+        if (oo[u] == 0) dv = on[u] ? v[u] : dv;
+    }
+    return sum;
+}
+
+template <int OP>
+__global__ __launch_bounds__(kBlock) void sdia_f32_kernel(int nrow, int nslice, int ngroups, int remap, const int *__restrict__ sd_ptr,
+                                                           const int *__restrict__ sd_off, const unsigned long long *__restrict__ sd_mask,
+                                                           const float *__restrict__ sd_val, const float *__restrict__ x,
+                                                           const float *__restrict__ b, float *__restrict__ y, float omega)
+{
+    const int gid = remap ? xcd_remap(blockIdx.x, ngroups, remap) : blockIdx.x;
+    if (gid >= ngroups) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int sl = gid * (kBlock / 64) + w;
+    if (sl >= nslice) return;
+    int row = sl * 64 + lane;
+    const bool has_row = row < nrow;
+    if (!has_row) row = nrow - 1;
+    const int s0 = __builtin_amdgcn_readfirstlane(sd_ptr[sl]);
+    const int nd = __builtin_amdgcn_readfirstlane(sd_ptr[sl + 1]) - s0;
+    const float bi = b[row];
+    const float xi = (OP == OP_JACOBI) ? x[row] : 0.f;
+    const int *off = sd_off + s0;
+    const unsigned long long *mask = sd_mask + s0;
+    const float *vp = sd_val + (size_t)s0 * 64 + lane;
+    float sum = 0.f, dv = 0.f;
+    int d = 0;
+    for (; d + 8 <= nd; d += 8) sum = sdia32_chunk<8>(off, mask, vp, x, d, row, lane, dv, sum);
+    switch (nd - d) {
+    case 7: sum = sdia32_chunk<7>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    case 6: sum = sdia32_chunk<6>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    case 5: sum = sdia32_chunk<5>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    case 4: sum = sdia32_chunk<4>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    case 3: sum = sdia32_chunk<3>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    case 2: sum = sdia32_chunk<2>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    case 1: sum = sdia32_chunk<1>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    default: break;
+    }
+    if (!has_row) return;
+    const float h = bi - sum;
+    if constexpr (OP == OP_JACOBI)
+        y[row] = xi + omega * h / dv;
+    else
+        y[row] = h;
+}
+
+__global__ __launch_bounds__(kBlock) void jacobi_zero_f32_kernel(int n, const float *__restrict__ b, const float *__restrict__ d,
+                                                                  float omega, float *__restrict__ x)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) x[i] = omega * b[i] / d[i];
+}
+
+// short rows (restriction of an aggregation: 1-2 entries): one thread per row
+__global__ __launch_bounds__(kBlock) void csr_rows_f32_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                               const double *__restrict__ val, const float *__restrict__ x,
+                                                               float *__restrict__ y, int add)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        float s = 0.f;
+        for (int j = rowptr[i]; j < rowptr[i + 1]; ++j) s += (float)val[j] * x[col[j]];
+        y[i] = add ? s + y[i] : s;
+    }
+}
+
+// fallback for (small, coarse) levels without a sliced-diagonal mirror: one thread per CSR row,
+// fp64 values converted on the fly
+template <int OP>
+__global__ __launch_bounds__(kBlock) void csr_f32_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                          const double *__restrict__ val, const float *__restrict__ diag,
+                                                          const float *__restrict__ x, const float *__restrict__ b, float *__restrict__ y,
+                                                          float omega)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        float s = 0.f;
+        for (int j = rowptr[i]; j < rowptr[i + 1]; ++j) s += (float)val[j] * x[col[j]];
+        const float h = b[i] - s;
+        if constexpr (OP == OP_JACOBI)
+            y[i] = x[i] + omega * h / diag[i];
+        else
+            y[i] = h;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void prolong_agg_f32_kernel(int n, const int *__restrict__ agg, const float *__restrict__ xc,
+                                                                  float *__restrict__ xf)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) xf[i] = xc[agg[i]] + xf[i];
+}
+
+__global__ __launch_bounds__(kBlock) void gemv_f32_kernel(int n, const float *__restrict__ M, const float *__restrict__ b,
+                                                           float *__restrict__ x)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float *__restrict__ m = M + (size_t)row * n;
+    float acc = 0.f;
+    for (int j = lane; j < n; j += 64) acc += m[j] * b[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) x[row] = acc;
+}
+
+__global__ __launch_bounds__(kBlock) void cvt_d2f_kernel(long n, const double *__restrict__ in, float *__restrict__ out)
+{
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) out[i] = (float)in[i];
+}
+
+__global__ __launch_bounds__(kBlock) void cvt_f2d_dot_kernel(int n, const float *__restrict__ z32, const double *__restrict__ r,
+                                                              double *__restrict__ z, double *__restrict__ partial)
+{
+    __shared__ double red[kBlock / 64];
+    double acc = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const double zi = (double)z32[i];
+        z[i] = zi;
+        acc += zi * r[i];
+    }
+    const double t = block_sum(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
 KernelConfig g_cfg;
 
 template <int OP, int TAG>
@@ -1022,6 +1170,75 @@ void launch_bicg_xr(int n, const double *scal, const double *p1, const double *s
 void launch_bicg_p(int n, const double *scal, const double *r, const double *Ap, double *p, hipStream_t st)
 {
     hipLaunchKernelGGL(bicg_p_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, st, n, scal, r, Ap, p);
+}
+
+void launch_sdia_f32(const SdiaF32 &A, CsrOp op, const float *x, const float *b, float *y, float omega, hipStream_t st)
+{
+    const int ngroups = (A.nslice + 3) / 4;
+    if (ngroups <= 0) return;
+    // float layout working set vs the Infinity Cache (same rule as the fp64 policy)
+    const size_t bytes = (size_t)A.slots * 64 * 4 + (size_t)A.nrow * 12;
+    const int remap = bytes > (240u << 20) ? 16 : 1;
+    const int grid = remap_grid(ngroups, remap);
+    if (op == OP_JACOBI)
+        hipLaunchKernelGGL((sdia_f32_kernel<OP_JACOBI>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.nslice, ngroups, remap, A.sd_ptr, A.sd_off, A.sd_mask, A.val, x, b, y, omega);
+    else
+        hipLaunchKernelGGL((sdia_f32_kernel<OP_RESID>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.nslice, ngroups, remap, A.sd_ptr, A.sd_off, A.sd_mask, A.val, x, b, y, omega);
+}
+
+void launch_csr_f32(const DevCsr &A, CsrOp op, const float *diag, const float *x, const float *b, float *y, float omega, hipStream_t st)
+{
+    if (A.nrow <= 0) return;
+    if (op == OP_JACOBI)
+        hipLaunchKernelGGL((csr_f32_kernel<OP_JACOBI>), dim3(ew_grid(A.nrow)), dim3(kBlock), 0, st, A.nrow, A.rowptr, A.col, A.val, diag, x, b, y, omega);
+    else
+        hipLaunchKernelGGL((csr_f32_kernel<OP_RESID>), dim3(ew_grid(A.nrow)), dim3(kBlock), 0, st, A.nrow, A.rowptr, A.col, A.val, diag, x, b, y, omega);
+}
+
+void launch_jacobi_zero_f32(int n, const float *b, const float *d, float omega, float *x, hipStream_t st)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(jacobi_zero_f32_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, st, n, b, d, omega, x);
+}
+
+void launch_restrict_f32(int nc, const int *rowptr, const int *col, const double *val, const float *r, float *bc, hipStream_t st)
+{
+    if (nc <= 0) return;
+    hipLaunchKernelGGL(csr_rows_f32_kernel, dim3(ew_grid(nc)), dim3(kBlock), 0, st, nc, rowptr, col, val, r, bc, 0);
+}
+
+void launch_prolong_csr_f32(int n, const int *rowptr, const int *col, const double *val, const float *xc, float *xf, hipStream_t st)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(csr_rows_f32_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, st, n, rowptr, col, val, xc, xf, 1);
+}
+
+void launch_prolong_agg_f32(int n, const int *agg, const float *xc, float *xf, hipStream_t st)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(prolong_agg_f32_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, st, n, agg, xc, xf);
+}
+
+void launch_gemv_f32(int n, const float *M, const float *b, float *x, hipStream_t st)
+{
+    if (n <= 0) return;
+    const int rows_per_blk = kBlock / 64;
+    hipLaunchKernelGGL(gemv_f32_kernel, dim3((n + rows_per_blk - 1) / rows_per_blk), dim3(kBlock), 0, st, n, M, b, x);
+}
+
+void launch_cvt_d2f(long n, const double *in, float *out, hipStream_t st)
+{
+    if (n <= 0) return;
+    long g = (n + kBlock * 4 - 1) / (kBlock * 4);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(cvt_d2f_kernel, dim3((unsigned)g), dim3(kBlock), 0, st, n, in, out);
+}
+
+void launch_cvt_f2d_dot(int n, const float *z32, const double *r64, double *z64, double *partial, int *nblk, hipStream_t st)
+{
+    const int g = ew_grid(n);
+    *nblk = g;
+    hipLaunchKernelGGL(cvt_f2d_dot_kernel, dim3(g), dim3(kBlock), 0, st, n, z32, r64, z64, partial);
 }
 
 }  // namespace sparsh

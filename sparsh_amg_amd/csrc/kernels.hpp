@@ -107,6 +107,29 @@ void launch_axpby(int n, double a, const double *x, double b, double *y, hipStre
 // partial sums of x.y (nblocks returned through *nblk)
 void launch_dot(int n, const double *x, const double *y, double *partial, int *nblk, hipStream_t st);
 
+// ---- fp32 preconditioner hierarchy (opt-in; SURVEY §8f-4 "mixed precision"): the V-cycle runs on a
+// float copy of the sliced-diagonal layout with float vectors, the Krylov loop stays fp64.
+struct SdiaF32 {
+    int nrow = 0, nslice = 0;
+    const int *sd_ptr = nullptr;                  // shared with the fp64 mirror
+    const int *sd_off = nullptr;
+    const unsigned long long *sd_mask = nullptr;
+    float *val = nullptr;                         // per slot 64 floats
+    long slots = 0;
+};
+// op: OP_JACOBI (y = x + omega (b - A x)/d) or OP_RESID (y = b - A x); all vectors float
+void launch_sdia_f32(const SdiaF32 &A, CsrOp op, const float *x, const float *b, float *y, float omega, hipStream_t st);
+// same two ops for a level that has no sliced-diagonal mirror (thread per CSR row; coarse levels only)
+void launch_csr_f32(const DevCsr &A, CsrOp op, const float *diag, const float *x, const float *b, float *y, float omega, hipStream_t st);
+void launch_jacobi_zero_f32(int n, const float *b, const float *d, float omega, float *x, hipStream_t st);
+void launch_restrict_f32(int nc, const int *rowptr, const int *col, const double *val, const float *r, float *bc, hipStream_t st);
+void launch_prolong_agg_f32(int n, const int *agg, const float *xc, float *xf, hipStream_t st);
+void launch_prolong_csr_f32(int n, const int *rowptr, const int *col, const double *val, const float *xc, float *xf, hipStream_t st);
+void launch_gemv_f32(int n, const float *M, const float *b, float *x, hipStream_t st);
+void launch_cvt_d2f(long n, const double *in, float *out, hipStream_t st);
+// z64 = (double) z32 ; partial += z64 * r64   (preconditioned residual back to fp64 + fused z.r)
+void launch_cvt_f2d_dot(int n, const float *z32, const double *r64, double *z64, double *partial, int *nblk, hipStream_t st);
+
 // device-resident scalar slots used by the Krylov loops
 enum Slot : int {
     S_RZ = 0, S_PAP, S_ALPHA, S_NALPHA, S_BETA, S_RR, S_RES, S_ZR,

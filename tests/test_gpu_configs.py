@@ -254,3 +254,40 @@ def test_unsymmetric_convection_diffusion_bicgstab():
         true_dev, true_orc = np.linalg.norm(b - M @ x), np.linalg.norm(b - M @ xo)
         assert h[-1] <= 1e-8 and true_dev <= max(1.001e-8, 5 * true_orc), (method, true_dev, true_orc)
         assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
+
+
+@pytest.mark.parametrize("gen", ["p3d", "p2d"])
+def test_fp32_preconditioner_mode(gen):
+    """Opt-in mixed precision: float V-cycle inside the fp64 CG.  Not a parity mode --
+    checked for what it promises: same solution to the same tolerance, about the same iteration
+    count, fp64 residual recurrence intact."""
+    rp, ci, v = problems.poisson3d(48) if gen == "p3d" else problems.poisson2d(300)
+    n = len(rp) - 1
+    import scipy.sparse as sp
+
+    S = sp.csr_matrix((v, ci, rp), shape=(n, n))
+    b = np.ones(n)
+    A64 = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET))
+    x64 = np.zeros(n)
+    h64, rc = A64.solve("pcg", b, x64)
+    A32 = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET, precond_fp32=1))
+    x32 = np.zeros(n)
+    h32, rc32 = A32.solve("pcg", b, x32)
+    assert rc == 0 and rc32 == 0
+    assert len(h32) <= len(h64) + 3, (len(h32), len(h64))
+    assert np.allclose(h32[:3], h64[:3], rtol=1e-3)  # same preconditioner up to float rounding
+    assert np.linalg.norm(b - S @ x32) <= 5e-8
+    assert np.linalg.norm(x32 - x64) <= 1e-7 * np.linalg.norm(x64)
+    # the fp64 entry points are untouched by the mode: AMG stand-alone still matches bitwise
+    xa, xb = np.zeros(n), np.zeros(n)
+    A64.vcycle(b, xa, iterations=2)
+    A32.vcycle(b, xb, iterations=2)
+    assert np.array_equal(xa, xb)
+
+
+def test_fp32_preconditioner_needs_sliced_diagonals():
+    rp, ci, v = problems.random_spd(150000, 9, seed=11)
+    A = sa.sp_matrix_mg(rp, ci, v)
+    with pytest.raises(sa.SparshError) as e:
+        A.setup(sa.default_params(**QUIET, precond_fp32=1))
+    assert e.value.code == sa.SPARSH_EINVAL and "sliced-diagonal" in str(e.value)
