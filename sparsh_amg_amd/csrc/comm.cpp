@@ -7,6 +7,8 @@
 
 #include <rccl/rccl.h>
 
+#include "kernels.hpp"
+
 namespace sparsh {
 
 // ------------------------------------------------------------------ single rank
@@ -41,6 +43,7 @@ public:
     bool exchange(const DevPlan &p, double *vec, hipStream_t st) override
     {
         if (p.recv.empty() && p.send.empty()) return true;
+        if (p.nsend > 0 && p.need_pack) launch_pack(p.nsend, p.send_idx, vec, p.sendbuf, st);
         if (!ok(ncclGroupStart(), "ncclGroupStart")) return false;
         for (const HaloSeg &s : p.send) {
             const double *src = s.start >= 0 ? vec + s.start : p.sendbuf + s.off;
@@ -113,6 +116,7 @@ struct ThreadGroup {
     long generation = 0;
     std::vector<const DevPlan *> plans;
     std::vector<double *> vecs;
+    std::vector<hipEvent_t> pub, done;  // per rank: "my boundary data is ready" / "my pulls are finished"
     std::vector<double *> ptrs;
     std::vector<std::vector<double>> host;
     void wait()
@@ -136,23 +140,47 @@ ThreadGroup *thread_group_create(int nranks)
     g->plans.assign((size_t)nranks, nullptr);
     g->vecs.assign((size_t)nranks, nullptr);
     g->ptrs.assign((size_t)nranks, nullptr);
+    g->pub.assign((size_t)nranks, nullptr);
+    g->done.assign((size_t)nranks, nullptr);
     g->host.resize((size_t)nranks);
     return g;
 }
 
-void thread_group_destroy(ThreadGroup *g) { delete g; }
+void thread_group_destroy(ThreadGroup *g)
+{
+    if (!g) return;
+    for (hipEvent_t e : g->pub)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g->done)
+        if (e) (void)hipEventDestroy(e);
+    delete g;
+}
 
 namespace {
 class ThreadComm : public Comm {
 public:
     ThreadGroup *g = nullptr;
+    // Stream-asynchronous pull exchange: the host threads only rendezvous to trade pointers and
+    // event handles; all data movement and all ordering is expressed with stream events, exactly as
+    // the engine has to express it for RCCL.  A missing dependency in the engine (e.g. a kernel that
+    // does not wait for the halo) therefore shows up as wrong data in the virtual-rank tests.
     bool exchange(const DevPlan &p, double *vec, hipStream_t st) override
     {
-        // publish my packed send buffer, then pull my halo segments out of the peers' buffers
-        (void)hipStreamSynchronize(st);
+        if (!g->pub[rank]) {
+            (void)hipEventCreateWithFlags(&g->pub[rank], hipEventDisableTiming);
+            (void)hipEventCreateWithFlags(&g->done[rank], hipEventDisableTiming);
+        }
+        // peers may still be pulling the previous exchange's data out of my sendbuf
+        g->wait();
+        if (primed)
+            for (int r = 0; r < size; ++r)
+                if (r != rank && g->done[r]) (void)hipStreamWaitEvent(st, g->done[r], 0);
+        if (p.nsend > 0 && p.need_pack) launch_pack(p.nsend, p.send_idx, vec, p.sendbuf, st);
+        (void)hipEventRecord(g->pub[rank], st);
         g->plans[rank] = &p;
         g->vecs[rank] = vec;
-        g->wait();
+        g->wait();  // every rank's data-ready event is enqueued and its pointers are published
+        bool okp = true;
         for (const HaloSeg &r : p.recv) {
             const DevPlan *q = g->plans[r.peer];
             const HaloSeg *src = nullptr;
@@ -160,16 +188,22 @@ public:
                 if (s.peer == rank) src = &s;
             if (!src || src->cnt != r.cnt) {
                 error = "thread comm: send/recv plans disagree";
-                g->wait();
-                return false;
+                okp = false;
+                continue;
             }
+            (void)hipStreamWaitEvent(st, g->pub[r.peer], 0);
             const double *from = src->start >= 0 ? g->vecs[r.peer] + src->start : q->sendbuf + src->off;
             (void)hipMemcpyAsync(vec + p.nloc + r.off, from, (size_t)r.cnt * sizeof(double), hipMemcpyDeviceToDevice, st);
         }
-        (void)hipStreamSynchronize(st);
-        g->wait();
-        return true;
+        (void)hipEventRecord(g->done[rank], st);
+        g->wait();  // every rank's pulls are enqueued
+        // completion of this exchange on st must also mean: peers have finished reading my data
+        for (const HaloSeg &s : p.send)
+            if (g->done[s.peer]) (void)hipStreamWaitEvent(st, g->done[s.peer], 0);
+        primed = true;
+        return okp;
     }
+    bool primed = false;
     bool allreduce_sum(double *dev, int n, hipStream_t st) override
     {
         std::vector<double> &mine = g->host[rank];

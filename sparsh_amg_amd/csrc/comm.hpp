@@ -28,8 +28,11 @@ class Comm {
 public:
     virtual ~Comm() = default;
     int rank = 0, size = 1;
-    // vec holds nloc own entries followed by room for nhalo received ones; non-contiguous send
-    // segments are already packed into sendbuf, contiguous ones (start >= 0) go out of vec in place
+    // vec holds nloc own entries followed by room for nhalo received ones.  Packs the non-contiguous
+    // send segments into sendbuf (contiguous ones, start >= 0, go out of vec in place), then moves
+    // the data.  Everything is enqueued on st; on return nothing has necessarily happened yet.
+    // When the work queued on st up to here has completed, this rank's halo has landed AND every
+    // peer has finished reading this rank's boundary entries (send + receive semantics).
     virtual bool exchange(const DevPlan &p, double *vec, hipStream_t st) = 0;
     // in-place sum over ranks of n doubles in device memory
     virtual bool allreduce_sum(double *dev, int n, hipStream_t st) = 0;

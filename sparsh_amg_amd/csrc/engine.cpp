@@ -524,7 +524,6 @@ double Engine::read_hist(int it)
 bool Engine::halo(const DevPlan &p, double *vec)
 {
     if (!dist_) return true;
-    if (p.nsend > 0 && p.need_pack) launch_pack(p.nsend, p.send_idx, vec, p.sendbuf, st_);
     if (!comm_->exchange(p, vec, st_)) {
         error = "halo exchange failed: " + comm_->error;
         return false;
@@ -546,7 +545,6 @@ int Engine::apply_A(DevLevel &L, CsrOp op, CsrArgs a)
     (void)hipEventRecord(ev_ready_, st_);
     (void)hipStreamWaitEvent(st2_, ev_ready_, 0);
     const DevPlan &p = L.planA;
-    if (p.nsend > 0 && p.need_pack) launch_pack(p.nsend, p.send_idx, xin, p.sendbuf, st2_);
     if (!comm_->exchange(p, xin, st2_)) error = "halo exchange failed: " + comm_->error;
     (void)hipEventRecord(ev_halo_, st2_);
     a.slice_list = L.A.int_list;
