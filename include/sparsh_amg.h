@@ -65,7 +65,7 @@ typedef struct sparsh_params {
     int replicate_rows; /* multi-GPU: levels with at most this many rows are held and computed by every
                            rank (no halo exchange below that size)            [SPARSH_REPLICATE_ROWS] */
     int precond_fp32;   /* 0 (default): everything fp64, bitwise parity with the reference's arithmetic.
-                           1: SPARSH_PCG runs its V-cycle on a float copy of the hierarchy (float values
+                           1: SPARSH_PCG / SPARSH_PBICG run their V-cycle on a float copy of the hierarchy (float values
                            and vectors; needs the sliced-diagonal layout on every level, one GPU) while
                            the CG recurrences, residuals and the stopping test stay fp64.  Not a parity
                            mode: a different (cheaper) preconditioner, same solution to tol.

@@ -933,7 +933,10 @@ int Engine::bicg(const double *b, double *x, int max_iters, double *hist, int hi
             break;
         }
         const double *p1 = p;
-        if (precond) {
+        if (precond && f32_ready_) {
+            vcycle_f32(p, p1buf, part0_, &nb);  // float hierarchy (opt-in), fp64 in/out
+            p1 = p1buf;
+        } else if (precond) {
             vcycle(p, true, nullptr, nullptr);  // p1 = 0 ; p1 = V(p)
             launch_copy(n, lev_[0].x, p1buf, st_);
             p1 = p1buf;
@@ -943,7 +946,10 @@ int Engine::bicg(const double *b, double *x, int max_iters, double *hist, int hi
         finalize(FIN_BICG_ALPHA, part0_, part1_, nb, 0, nullptr, 0);
         launch_bicg_s(n, scal_, r, Ap, s, st_);
         const double *s1 = s;
-        if (precond) {
+        if (precond && f32_ready_) {
+            vcycle_f32(s, work_[7], part0_, &nb);
+            s1 = work_[7];
+        } else if (precond) {
             vcycle(s, true, nullptr, nullptr);  // s1 = 0 ; s1 = V(s)
             s1 = lev_[0].x;
         }

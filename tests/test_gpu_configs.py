@@ -278,6 +278,9 @@ def test_fp32_preconditioner_mode(gen):
     assert np.allclose(h32[:3], h64[:3], rtol=1e-3)  # same preconditioner up to float rounding
     assert np.linalg.norm(b - S @ x32) <= 5e-8
     assert np.linalg.norm(x32 - x64) <= 1e-7 * np.linalg.norm(x64)
+    xb32 = np.zeros(n)
+    hb32, rcb = A32.solve("pbicg", b, xb32)  # the mode also serves AMG-BiCGStab
+    assert rcb == 0 and np.linalg.norm(b - S @ xb32) <= 5e-8 and np.linalg.norm(xb32 - x64) <= 1e-7 * np.linalg.norm(x64)
     # the fp64 entry points are untouched by the mode: AMG stand-alone still matches bitwise
     xa, xb = np.zeros(n), np.zeros(n)
     A64.vcycle(b, xa, iterations=2)
