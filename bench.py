@@ -218,6 +218,19 @@ def main():
     it_bytes = vcycle_bytes(levels, sweeps) + (12 * nnz + 20 * n) + 2 * 16 * n + 8 * n + 3 * 24 * n
     its_per_s = args.steps / elapsed * (world if mode == "replicas" else 1)
 
+    # the metric's second half: plain SpMV y = A x on the finest level (HIP events, 20 launches, outside
+    # the timed region), priced with the CSR model 12*nnz + 20*n of SURVEY §8d
+    spmv = None
+    if mode != "replicas":
+        try:
+            t_spmv = A.bench_op("spmv", 0, 20)
+            sp_bytes = 12 * pr["nnz"] + 20 * pr["nrow"]
+            spmv = {"us": round(t_spmv * 1e6, 2), "GBps": round(sp_bytes / t_spmv / 1e9, 1),
+                    "frac_of_8TBps": round(sp_bytes / t_spmv / 1e9 / HBM_PEAK_GBS, 4), "bytes_csr_model": sp_bytes,
+                    "rows": pr["nrow"], "nnz": pr["nnz"]}
+        except Exception as e:  # noqa: BLE001
+            spmv = {"error": repr(e)}
+
     # outside the timed region: a complete solve to the reference tolerance on the same hierarchy
     log("full solve to tol=1e-8")
     A.set_stopping(1e-8, 100000, 1)
@@ -306,6 +319,7 @@ def main():
                 "algorithmic_GB_per_iteration": round(it_bytes / 1e9, 3),
                 "solve_GBps": round(it_bytes * its_per_s / 1e9, 1),
                 "solve_frac_of_8TBps": round(it_bytes * its_per_s / 1e9 / HBM_PEAK_GBS, 4),
+                "spmv_finest_level": spmv,
                 "residual_after_timed_steps": float(hist[-1]),
                 "full_solve_to_1e-8": full,
                 "setup_seconds_host": round(A.setup_seconds, 2),

@@ -67,6 +67,9 @@ struct DBuf {
 #define REQUIRE_LEVEL(h, l) \
     if ((l) < 0 || (l) >= (int)(h)->eng->host().levels.size()) return fail(SPARSH_EINVAL, "level out of range")
 
+#define REQUIRE_SINGLE(h) \
+    if ((h)->eng->distributed()) return fail(SPARSH_ESTATE, "operator-level entry points are single-GPU test hooks (host vectors carry no halo)")
+
 #define REQUIRE_HOST(h)                                               \
     if (!(h) || !(h)->eng) return fail(SPARSH_EINVAL, "null handle"); \
     if (!(h)->eng->host_ready()) return fail(SPARSH_ESTATE, "sparsh_setup / sparsh_setup_host has not been called (or failed)")
@@ -434,6 +437,7 @@ int sparsh_krylov_history(sparsh_handle h, double *hist, int hist_cap, int *iter
 int sparsh_op_spmv(sparsh_handle h, int level, const double *x, double *y)
 {
     REQUIRE_READY(h);
+    REQUIRE_SINGLE(h);
     REQUIRE_LEVEL(h, level);
     Engine &E = *h->eng;
     const DevLevel &L = E.level(level);
@@ -445,6 +449,7 @@ int sparsh_op_spmv(sparsh_handle h, int level, const double *x, double *y)
 int sparsh_op_jacobi(sparsh_handle h, int level, const double *b, double *x, int sweeps, int x_is_zero)
 {
     REQUIRE_READY(h);
+    REQUIRE_SINGLE(h);
     REQUIRE_LEVEL(h, level);
     if (sweeps < 0) return fail(SPARSH_EINVAL, "sweeps < 0");
     Engine &E = *h->eng;
@@ -457,6 +462,7 @@ int sparsh_op_jacobi(sparsh_handle h, int level, const double *b, double *x, int
 int sparsh_op_residual(sparsh_handle h, int level, const double *b, const double *x, double *r)
 {
     REQUIRE_READY(h);
+    REQUIRE_SINGLE(h);
     REQUIRE_LEVEL(h, level);
     Engine &E = *h->eng;
     const size_t n = (size_t)E.level(level).n;
@@ -468,6 +474,7 @@ int sparsh_op_residual(sparsh_handle h, int level, const double *b, const double
 int sparsh_op_resnorm(sparsh_handle h, int level, const double *b, const double *x, double *nrm)
 {
     REQUIRE_READY(h);
+    REQUIRE_SINGLE(h);
     REQUIRE_LEVEL(h, level);
     Engine &E = *h->eng;
     const size_t n = (size_t)E.level(level).n;
@@ -479,6 +486,7 @@ int sparsh_op_resnorm(sparsh_handle h, int level, const double *b, const double 
 int sparsh_op_restrict(sparsh_handle h, int level, const double *r, double *bc)
 {
     REQUIRE_READY(h);
+    REQUIRE_SINGLE(h);
     REQUIRE_LEVEL(h, level);
     if (level + 1 >= h->eng->nlevels()) return fail(SPARSH_EINVAL, "no coarser level");
     Engine &E = *h->eng;
@@ -490,6 +498,7 @@ int sparsh_op_restrict(sparsh_handle h, int level, const double *r, double *bc)
 int sparsh_op_prolong(sparsh_handle h, int level, const double *xc, double *xf)
 {
     REQUIRE_READY(h);
+    REQUIRE_SINGLE(h);
     REQUIRE_LEVEL(h, level);
     if (level + 1 >= h->eng->nlevels()) return fail(SPARSH_EINVAL, "no coarser level");
     Engine &E = *h->eng;
@@ -511,6 +520,7 @@ int sparsh_op_coarse(sparsh_handle h, const double *b, double *x)
 int sparsh_op_dot(sparsh_handle h, int n, const double *x, const double *y, double *out)
 {
     REQUIRE_READY(h);
+    REQUIRE_SINGLE(h);
     if (n <= 0) return fail(SPARSH_EINVAL, "n <= 0");
     Engine &E = *h->eng;
     DBuf dx(E, (size_t)n, x), dy(E, (size_t)n, y);
@@ -529,6 +539,7 @@ int sparsh_op_nrm2(sparsh_handle h, int n, const double *x, double *out)
 int sparsh_op_axpby(sparsh_handle h, int n, double a, const double *x, double bcoef, double *y)
 {
     REQUIRE_READY(h);
+    REQUIRE_SINGLE(h);
     if (n <= 0) return fail(SPARSH_EINVAL, "n <= 0");
     Engine &E = *h->eng;
     DBuf dx(E, (size_t)n, x), dy(E, (size_t)n, y);
@@ -547,7 +558,9 @@ int sparsh_bench_op(sparsh_handle h, int op, int level, int reps, double *avg_se
     const bool has_coarse = level + 1 < E.nlevels();
     if ((op == 3 || op == 4) && !has_coarse) return fail(SPARSH_EINVAL, "no coarser level");
     const size_t nc = has_coarse ? (size_t)E.level(level + 1).n : 1;
-    DBuf x(E, n), y(E, n), b(E, n), c(E, nc);
+    // multi-GPU: operator inputs carry the halo behind the own entries
+    const size_t xh = (size_t)std::max(L.planA.nhalo, L.planR.nhalo), ch = (size_t)L.planP.nhalo;
+    DBuf x(E, n + xh), y(E, n), b(E, n), c(E, nc + ch);
     std::vector<double> ones(std::max(n, nc), 1.0);
     (void)hipMemcpy(x.p, ones.data(), n * 8, hipMemcpyHostToDevice);
     (void)hipMemcpy(b.p, ones.data(), n * 8, hipMemcpyHostToDevice);
