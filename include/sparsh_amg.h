@@ -183,6 +183,7 @@ int sparsh_bench_op(sparsh_handle h, int op, int level, int reps, double *avg_se
 /* device memory helpers so a host language needs no HIP binding of its own */
 int sparsh_dev_alloc(sparsh_handle h, long nbytes, void **out);
 int sparsh_dev_free(sparsh_handle h, void *p);
+int sparsh_dev_fill(sparsh_handle h, double *dst_dev, long n, double value); /* on the engine's stream (thrust::fill of the reference) */
 int sparsh_h2d(sparsh_handle h, void *dst_dev, const void *src, long nbytes);
 int sparsh_d2h(sparsh_handle h, void *dst, const void *src_dev, long nbytes);
 int sparsh_sync(sparsh_handle h);

@@ -117,6 +117,7 @@ def _load():
         "sparsh_bench_op": (C.c_int, [H, C.c_int, C.c_int, C.c_int, c_dbl_p]),
         "sparsh_dev_alloc": (C.c_int, [H, C.c_long, P(C.c_void_p)]),
         "sparsh_dev_free": (C.c_int, [H, C.c_void_p]),
+        "sparsh_dev_fill": (C.c_int, [H, C.c_void_p, C.c_long, C.c_double]),
         "sparsh_h2d": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_long]),
         "sparsh_d2h": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_long]),
         "sparsh_sync": (C.c_int, [H]),
@@ -342,6 +343,9 @@ class sp_matrix_mg:
 
     def dev_free(self, p):
         _check(lib.sparsh_dev_free(self._h, p))
+
+    def dev_fill(self, dptr, n, value=0.0):
+        _check(lib.sparsh_dev_fill(self._h, dptr, n, value))
 
     def h2d(self, dptr, arr):
         arr = np.ascontiguousarray(arr)

@@ -623,6 +623,14 @@ int sparsh_dev_free(sparsh_handle h, void *p)
     return SPARSH_OK;
 }
 
+int sparsh_dev_fill(sparsh_handle h, double *dst_dev, long n, double value)
+{
+    if (!h || !h->eng || !h->eng->stream()) return fail(SPARSH_EINVAL, "null handle or no stream (call sparsh_setup first)");
+    if (n < 0 || n > 0x7fffffffL) return fail(SPARSH_EINVAL, "bad length");
+    launch_fill((int)n, value, dst_dev, h->eng->stream());
+    return SPARSH_OK;
+}
+
 int sparsh_h2d(sparsh_handle h, void *dst_dev, const void *src, long nbytes)
 {
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
