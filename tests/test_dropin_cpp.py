@@ -25,7 +25,8 @@ def test_cpp_entry_points_exported():
         assert re.search(rf"\bT {name}\(", out), name
     for cls in ("AMG_solver::AMG_solver_setup_jacobi(sp_matrix_mg&)", "AMG_solver::AMG_solve_jacobi(double*&, double*&, int)",
                 "AMG_GPU1_solver::AMG_Solve(double*, double*, int)", "AMG_GPU1_solver::helper(double*, double*, int)",
-                "AMG_GPU_solver::AMG_GPU_solve(double*, double*, int)"):
+                "AMG_GPU_solver::AMG_GPU_solve(double*, double*, int)", "sp_matrix_gpu::sp_matrix_gpu(sp_matrix_mg&)",
+                "sp_matrix_gpu::smooth_jacobi(double*, double*, double*, ihipStream_t*, int)", "gpu_swap_pointers(sp_matrix_gpu*&, sp_matrix_gpu*&)"):
         assert cls in out, cls
     for cls in ("sp_matrix::sp_matrix(int, int, int)", "sp_matrix_mg::sp_matrix_fill()", "sp_matrix_mg::sp_matrix_fill_diagonal()",
                 "sp_matrix_mg::~sp_matrix_mg()", "sp_matrix_mg::scale_system(double*&)", "sp_matrix_mg::normalize_matrix()"):

@@ -88,6 +88,33 @@ def test_solver_objects_api(driver, tmp_path):
     assert m and float(m.group(1)) <= 1.001e-8
 
 
+def test_gpu_matrix_object_api(driver, tmp_path):
+    """sp_matrix_gpu::smooth_jacobi and residual() (device-operator layer of the reference API)
+    against the oracle's Jacobi / residual on the same operator."""
+    _, mf, rf, (rp, ci, v, b) = driver
+    exe = tmp_path / "gpu_matrix_objects"
+    cmd = ["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", f"-I{os.path.join(ROOT, 'include')}", "-I/opt/rocm/include",
+           os.path.join(ROOT, "tests", "cpp", "gpu_matrix_objects.cpp"), "-o", str(exe), f"-L{LIB_DIR}", "-lsparsh_amg", "-L/opt/rocm/lib",
+           "-lamdhip64", f"-Wl,-rpath,{LIB_DIR}", "-L/opt/rocm/lib/llvm/lib", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib/llvm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe), mf, rf], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    m = re.search(r"GPUMAT (\S+) (\S+) (\S+) (\S+) (\S+)", r.stdout)
+    assert m, r.stdout[-1500:]
+    O = oracle.Csr(rp, ci, v)
+    n = len(rp) - 1
+    x = 0.001 * (np.arange(n) % 17) - 0.003
+    r0 = oracle.residual(O, b, x)
+    x5 = oracle.jacobi(O, b, x, 4)      # iteration+1 = 5 sweeps
+    r5 = oracle.residual(O, b, x5)
+    x11 = oracle.jacobi(O, b, x5, 5)    # 6 more
+    r11 = oracle.residual(O, b, x11)
+    got = [float(m.group(k)) for k in range(1, 6)]
+    assert abs(got[0] - r0) <= 1e-12 * r0 and abs(got[1] - r5) <= 1e-12 * r5 and abs(got[2] - r11) <= 1e-12 * r11
+    assert got[3] == x11[0] and got[4] == x11[n // 2]  # sweeps are bitwise the oracle's
+
+
 def test_sor_entry_point_is_a_stub(driver):
     exe, mf, rf, _ = driver
     r = subprocess.run([exe, mf, rf, "sor"], capture_output=True, text=True, timeout=120)
