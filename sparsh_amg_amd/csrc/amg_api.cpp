@@ -69,7 +69,8 @@ void sp_matrix_mg::sp_matrix_fill()
     }
     sA = 0;
     des.type = 20;  // "general"
-    A1 = this;      // marks the matrix as registered
+    // A1 (the MKL handle of the reference) later holds the device mirror the building-block
+    // functions create on first use (csrc/blocks_api.cpp)
 }
 
 void sp_matrix_mg::sp_matrix_fill_diagonal()
@@ -90,8 +91,11 @@ void sp_matrix_mg::sp_matrix_fill_diagonal()
 }
 
 // Tolerates the explicit `A->~sp_matrix_mg()` of the reference's main.cpp:40 (pointers are reset).
+void sparsh_release_mirror(void *a1);  // blocks_api.cpp
+
 sp_matrix_mg::~sp_matrix_mg()
 {
+    if (A1) sparsh_release_mirror(A1);
     A1 = nullptr;
     delete[] diagonal;
     delete[] helper;
