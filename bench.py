@@ -218,7 +218,8 @@ def main():
     # bytes the chosen layout really has to move per sweep: values (+ column indices unless the
     # layout stores diagonals), b, x_i / gathered x once, x_new; the diagonal comes out of the
     # value stream for the mirrors
-    fmt_bytes = {3: 8 * stored + 24 * pr["nrow"], 2: 12 * stored + 4 * pr["nrow"] + 24 * pr["nrow"]}.get(fmt, jac_bytes)
+    slots, vblocks, meta_bytes = A.level_layout(0)
+    fmt_bytes = {3: 8 * stored + meta_bytes + 24 * pr["nrow"], 2: 12 * stored + 4 * pr["nrow"] + 24 * pr["nrow"]}.get(fmt, jac_bytes)
     roof = None
     if pr["launches"] > 0:
         avg = pr["seconds"] / pr["launches"]
@@ -239,6 +240,7 @@ def main():
                     "layout_bytes_per_launch, i.e. layout_GBps of real traffic",
             "layout_bytes_per_launch": fmt_bytes, "layout_GBps": round(fmt_bytes / avg / 1e9, 1),
             "layout_frac": round(fmt_bytes / avg / 1e9 / HBM_PEAK_GBS, 4),
+            "layout": {"slots": slots, "value_blocks": vblocks, "constant_slots": slots - vblocks, "descriptor_bytes": meta_bytes} if fmt == 3 else None,
         }
 
     # whole-iteration algorithmic bytes: V-cycle + SpMV + 2 dot + nrm2 + 3 axpy-type
@@ -274,6 +276,35 @@ def main():
         t_h = time.perf_counter() - t_h
         full["host_buffer_path_seconds"] = round(t_h, 4)
         full["host_buffer_path_iterations_per_s"] = round(len(hh) / t_h, 2)
+
+    # transparency: the same iterations with constant-slot folding switched off (every stored entry
+    # streams its 8-byte value, as for a variable-coefficient operator); residuals must be identical
+    general = None
+    if world == 1 and mode == "single" and slots > vblocks and os.environ.get("SPARSH_BENCH_NO_GENERAL", "0") != "1":
+        log("general-values layout run (constant-slot folding off)")
+        try:
+            sa.set_const_slots(False)
+            A2 = sa.sp_matrix_mg(rp, ci, v).setup(prm)
+        finally:
+            sa.set_const_slots(True)
+        b2 = A2.dev_alloc(8 * n)
+        x2 = A2.dev_alloc(8 * n)
+        A2.h2d(b2, b)
+        A2.h2d(x2, np.zeros(n))
+        A2.krylov_init_dev("pcg", b2, x2)
+        kk = min(args.steps, RESTART - 4)
+        A2.krylov_step_dev(3)
+        A2.sync()
+        t_g = time.perf_counter()
+        A2.krylov_step_dev(kk)
+        A2.sync()
+        t_g = time.perf_counter() - t_g
+        h2 = A2.krylov_history()
+        m2 = min(len(h2), len(hist))
+        general = {"iterations_per_s": round(kk / t_g, 2), "steps": kk, "jacobi_fine_us": round(A2.bench_op("jacobi", 0, 20) * 1e6, 2),
+                   "residual_history_identical": bool(np.array_equal(h2[:m2], hist[:m2])),
+                   "note": "constant-slot folding off: the layout a variable-coefficient operator gets (8 B per stored entry)"}
+        A2.close()
 
     # multi-GPU parity: rank 0 repeats the same iterations on ONE GPU (fresh handle, no transport)
     # and compares residual histories; the other ranks wait at the barrier below.
@@ -350,6 +381,7 @@ def main():
                 "residual_after_timed_steps": float(last_hist[-1]),
                 "solve_restarted_every": RESTART,
                 "full_solve_to_1e-8": full,
+                "general_values_layout": general,
                 "setup_seconds_host": round(A.setup_seconds, 2),
                 "generate_seconds": round(t_gen, 2),
             },

@@ -111,6 +111,18 @@ int sparsh_set_kernel_config(int kind, int vec, int nt, int remap);
  * (padding included). */
 int sparsh_level_format(sparsh_handle h, int level, int *kind, long *stored_entries);
 
+/* Sliced-diagonal layout of a level: number of (slice, diagonal) slots and how many of them own a
+ * 64-value block.  A slot whose present entries all carry the same value ("constant slot":
+ * constant-coefficient stencils and their aggregated coarse operators) keeps that value once in
+ * its header and owns no block; the arithmetic is unchanged (same products, same order).  Slices
+ * made of at most 8 constant slots are described by one fixed-stride 192-byte record (offsets,
+ * lane masks, constants, count) the kernel fetches with a single batch of scalar loads.
+ * meta_bytes = bytes of slice/slot descriptors one sweep reads.  All 0 when the level does not use
+ * the layout.  sparsh_set_const_slots(0) before sparsh_setup turns the folding off (A/B
+ * measurements; default on). */
+int sparsh_level_layout(sparsh_handle h, int level, long *slots, long *value_blocks, long *meta_bytes);
+int sparsh_set_const_slots(int enable);
+
 /* Host half of sparsh_setup only (coarsening, Galerkin products, coarse factorisation); needs
  * no GPU.  Enables the inspection calls below; solvers still require sparsh_setup. */
 int sparsh_setup_host(sparsh_handle h, const sparsh_params *p);

@@ -82,6 +82,8 @@ def _load():
         "sparsh_set_stopping": (C.c_int, [H, C.c_double, C.c_int, C.c_int]),
         "sparsh_set_kernel_config": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
         "sparsh_level_format": (C.c_int, [H, C.c_int, c_int_p, C.POINTER(C.c_long)]),
+        "sparsh_level_layout": (C.c_int, [H, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+        "sparsh_set_const_slots": (C.c_int, [C.c_int]),
         "sparsh_num_levels": (C.c_int, [H]),
         "sparsh_level_info": (C.c_int, [H, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p]),
         "sparsh_level_csr": (C.c_int, [H, C.c_int, C.c_int, c_int_p, c_int_p, c_dbl_p]),
@@ -156,6 +158,11 @@ def default_params(**kw) -> Params:
             raise AttributeError(f"sparsh_params has no field {k}")
         setattr(p, k, v)
     return p
+
+
+def set_const_slots(enable=True):
+    """Layout option read at setup (process-wide): fold constant diagonals of a slice into one scalar."""
+    _check(lib.sparsh_set_const_slots(int(bool(enable))))
 
 
 def set_kernel_config(kind=3, vec=True, nt=-1, remap=-1):
@@ -254,6 +261,13 @@ class sp_matrix_mg:
         k, e = C.c_int(), C.c_long()
         _check(lib.sparsh_level_format(self._h, level, C.byref(k), C.byref(e)))
         return k.value, e.value
+
+    def level_layout(self, level):
+        """(slots, value blocks, descriptor bytes) of the sliced-diagonal layout of this level; constant
+        slots own no value block."""
+        sl, vb, mb = C.c_long(), C.c_long(), C.c_long()
+        _check(lib.sparsh_level_layout(self._h, level, C.byref(sl), C.byref(vb), C.byref(mb)))
+        return sl.value, vb.value, mb.value
 
     def level_csr(self, level, which="A"):
         info = self.level_info(level)

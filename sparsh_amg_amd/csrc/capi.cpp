@@ -188,9 +188,9 @@ int sparsh_level_format(sparsh_handle h, int level, int *kind, long *stored_entr
     const KernelConfig &c = kernel_config();
     int k = 0;
     long e = A.nnz;
-    if (c.kind == 3 && A.sd_val) {
+    if (c.kind == 3 && A.has_sdia()) {
         k = 3;
-        e = A.sd_slots * 64;
+        e = A.sd_vblocks * 64;  // values actually stored: constant slots own no block
     } else if (c.kind >= 2 && A.sell_val) {
         k = 2;
         e = A.sell_entries;
@@ -199,6 +199,33 @@ int sparsh_level_format(sparsh_handle h, int level, int *kind, long *stored_entr
     }
     if (kind) *kind = k;
     if (stored_entries) *stored_entries = e;
+    return SPARSH_OK;
+}
+
+int sparsh_level_layout(sparsh_handle h, int level, long *slots, long *value_blocks, long *meta_bytes)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    const DevCsr &A = h->eng->level(level).A;
+    if (slots) *slots = A.has_sdia() ? A.sd_slots : 0;
+    if (value_blocks) *value_blocks = A.has_sdia() ? A.sd_vblocks : 0;
+    if (meta_bytes) {
+        // what one sweep reads besides values and vectors: per-slice records (192 B) where they exist
+        // (slices off the record path additionally read their 24 B/slot headers: counted for all slots
+        // only when there are no records), else sd_ptr + 24 B per slot
+        if (!A.has_sdia())
+            *meta_bytes = 0;
+        else if (A.sd_rec)
+            *meta_bytes = (long)A.nslice * kSdRecInts * 4 + A.sd_vblocks * 24;
+        else
+            *meta_bytes = (long)A.nslice * 4 + A.sd_slots * 24;
+    }
+    return SPARSH_OK;
+}
+
+int sparsh_set_const_slots(int enable)
+{
+    kernel_config().const_slots = enable != 0;
     return SPARSH_OK;
 }
 

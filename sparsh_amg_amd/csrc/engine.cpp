@@ -193,13 +193,88 @@ bool upload_sdia(Engine &E, const HostCsr &A, DevCsr &D)
             }
         }
     }
+    // constant slots: every present entry of the slot holds the same bit pattern -> keep one scalar,
+    // drop the 64-value block (the product v*x is the same multiplication, so results do not change)
+    std::vector<int> vidx((size_t)total, 0);
+    std::vector<double> cval((size_t)total, 0.0);
+    const bool fold = kernel_config().const_slots && !E.params().precond_fp32;  // the float mirror converts whole blocks
+#pragma omp parallel for schedule(static)
+    for (long q = 0; q < total; ++q) {
+        const unsigned long long m = mask[(size_t)q];
+        const double *blk = &val[(size_t)q * 64];
+        bool same = fold && m != 0;
+        double first = 0.0;
+        if (same) {
+            first = blk[__builtin_ctzll(m)];
+            for (int lane = 0; lane < 64 && same; ++lane)
+                if ((m >> lane) & 1ull) same = std::memcmp(&blk[lane], &first, sizeof(double)) == 0;
+        }
+        vidx[(size_t)q] = same ? -1 : 0;
+        cval[(size_t)q] = same ? first : 0.0;
+    }
+    long nblocks = 0;
+    for (long q = 0; q < total; ++q)
+        if (vidx[(size_t)q] == 0) vidx[(size_t)q] = (int)nblocks++;
+    if (nblocks < total) {  // compact the value stream in place (blocks only move towards the front)
+        for (long q = 0; q < total; ++q) {
+            const int k = vidx[(size_t)q];
+            if (k >= 0 && k != q) std::memmove(&val[(size_t)k * 64], &val[(size_t)q * 64], 64 * sizeof(double));
+        }
+        val.resize((size_t)std::max(nblocks, 1l) * 64);
+    }
+    // slices whose slots are all constant take the kernel's value-free path, slices without any
+    // constant slot the indirection-free one: flag both kinds in sd_ptr (readers mask the bits off)
+    if (total > kSdPtrMask) return true;  // flag bits need the room: keep ELL / CSR for such a level
+    std::vector<char> allconst((size_t)nslice, 0), noconst((size_t)nslice, 0);
+#pragma omp parallel for schedule(static)
+    for (int sl = 0; sl < nslice; ++sl) {
+        bool all = sp[(size_t)sl + 1] > sp[sl], none = true;
+        for (int q = sp[sl]; q < sp[(size_t)sl + 1]; ++q) {
+            all = all && vidx[(size_t)q] < 0;
+            none = none && vidx[(size_t)q] >= 0;
+        }
+        allconst[(size_t)sl] = all;
+        noconst[(size_t)sl] = none && sp[(size_t)sl + 1] > sp[sl];
+    }
+    for (int sl = 0; sl < nslice; ++sl) {
+        if (allconst[(size_t)sl]) sp[sl] |= kSdConstBit;
+        if (noconst[(size_t)sl]) sp[sl] |= kSdPlainBit;
+    }
+    // fixed-stride records of the value-free slices with at most 8 slots
+    std::vector<int> rec;
+    const bool with_rec = fold;
+    if (with_rec) {
+        rec.assign((size_t)nslice * kSdRecInts, 0);
+#pragma omp parallel for schedule(static)
+        for (int sl = 0; sl < nslice; ++sl) {
+            int *r = &rec[(size_t)sl * kSdRecInts];
+            const int q0 = sp[sl] & kSdPtrMask, q1 = sp[(size_t)sl + 1] & kSdPtrMask;
+            if (!allconst[(size_t)sl] || q1 - q0 > 8) {
+                r[40] = -1;
+                continue;
+            }
+            for (int q = q0; q < q1; ++q) {
+                r[q - q0] = off[(size_t)q];
+                std::memcpy(&r[8 + 2 * (q - q0)], &mask[(size_t)q], 8);
+                std::memcpy(&r[24 + 2 * (q - q0)], &cval[(size_t)q], 8);
+            }
+            r[40] = q1 - q0;
+        }
+    }
     D.nslice = nslice;
     D.sd_slots = total;
+    D.sd_vblocks = nblocks;
+    if (with_rec) {
+        D.sd_rec = upload(E, rec.data(), rec.size());
+        if (!D.sd_rec) return false;
+    }
     D.sd_ptr = upload(E, sp.data(), sp.size());
     D.sd_off = upload(E, off.data(), off.size());
     D.sd_mask = upload(E, mask.data(), mask.size());
+    D.sd_vidx = upload(E, vidx.data(), vidx.size());
+    D.sd_cval = upload(E, cval.data(), cval.size());
     D.sd_val = upload(E, val.data(), val.size());
-    return D.sd_ptr && D.sd_off && D.sd_mask && D.sd_val;
+    return D.sd_ptr && D.sd_off && D.sd_mask && D.sd_vidx && D.sd_cval && D.sd_val;
 }
 
 bool upload_csr(Engine &E, const HostCsr &A, DevCsr &D, bool with_sell)
@@ -428,7 +503,7 @@ bool Engine::setup_f32()
     // the float mirror exists for the sliced-diagonal layout; small coarse levels without it run a
     // simple per-row fallback, but a large level without it would make the mode pointless
     for (int l = 0; l + 1 < nl; ++l)
-        if (!lev_[l].A.sd_val && lev_[l].n > 100000) {
+        if (!lev_[l].A.has_sdia() && lev_[l].n > 100000) {
             error = "precond_fp32 needs the sliced-diagonal layout on the large levels (level " + std::to_string(l) + " does not qualify)";
             return false;
         }
@@ -446,7 +521,7 @@ bool Engine::setup_f32()
             f.diag = static_cast<float *>(dalloc(n * 4));
             if (!f.x2 || !f.r || !f.diag) return false;
             launch_cvt_d2f((long)n, d.diag, f.diag, st_);
-            if (d.A.sd_val) {
+            if (d.A.has_sdia()) {
                 f.A.nrow = d.n;
                 f.A.nslice = d.A.nslice;
                 f.A.sd_ptr = d.A.sd_ptr;
@@ -535,7 +610,7 @@ int Engine::apply_A(DevLevel &L, CsrOp op, CsrArgs a)
 {
     double *xin = const_cast<double *>(a.x);
     const KernelConfig &kc = kernel_config();
-    const bool sliced = (kc.kind == 3 && L.A.sd_val) || (kc.kind >= 2 && L.A.sell_val);
+    const bool sliced = (kc.kind == 3 && L.A.has_sdia()) || (kc.kind >= 2 && L.A.sell_val);
     if (!(dist_ && overlap_ && !L.replicated && sliced && L.A.nint > 0 && L.A.nbnd > 0 && st2_)) {
         halo(L.planA, xin);
         return launch_csr(L.A, op, a, L.fine, st_);

@@ -425,8 +425,62 @@ __global__ __launch_bounds__(kBlock) void sell_kernel(int nrow, int nslice, int 
 // slots are visited in exactly its CSR entry order; absent slots are skipped by the lane mask.
 template <int L, bool NT>
 __device__ __forceinline__ double sdia_chunk(const int *__restrict__ off, const unsigned long long *__restrict__ mask,
+                                             const int *__restrict__ vidx, const double *__restrict__ cval,
                                              const double *__restrict__ vp, const double *__restrict__ x, int d0, int row,
                                              int lane, double &dv, double sum)
+{
+    double v[L], xv[L];
+    bool on[L];
+    int oo[L];
+#pragma unroll
+    for (int u = 0; u < L; ++u) {
+        const int o = __builtin_amdgcn_readfirstlane(off[d0 + u]);
+        oo[u] = o;
+        const unsigned long long m = mask[d0 + u];  // wave-uniform address
+        on[u] = (m >> lane) & 1ull;
+        const int vi = __builtin_amdgcn_readfirstlane(vidx[d0 + u]);
+        if (vi >= 0)  // wave-uniform: the slot owns a value block
+            v[u] = ld_stream<NT>(vp + (size_t)vi * 64);
+        else          // constant slot: one scalar for the whole slice
+            v[u] = cval[d0 + u];
+        xv[u] = x[on[u] ? row + o : row];  // clamp absent lanes onto a valid address
+    }
+#pragma unroll
+    for (int u = 0; u < L; ++u) {
+        const double t = v[u] * xv[u];
+        sum = on[u] ? sum + t : sum;
+        if (oo[u] == 0) dv = on[u] ? v[u] : dv;  // wave-uniform test: the main diagonal's slot
+    }
+    return sum;
+}
+
+template <bool NT>
+__device__ __forceinline__ double sdia_row(const int *__restrict__ off, const unsigned long long *__restrict__ mask,
+                                           const int *__restrict__ vidx, const double *__restrict__ cval,
+                                           const double *__restrict__ vp, const double *__restrict__ x, int nd, int row, int lane,
+                                           double &dv)
+{
+    double sum = 0.0;
+    int d = 0;
+    for (; d + 8 <= nd; d += 8) sum = sdia_chunk<8, NT>(off, mask, vidx, cval, vp, x, d, row, lane, dv, sum);
+    switch (nd - d) {  // wave-uniform
+    case 7: sum = sdia_chunk<7, NT>(off, mask, vidx, cval, vp, x, d, row, lane, dv, sum); break;
+    case 6: sum = sdia_chunk<6, NT>(off, mask, vidx, cval, vp, x, d, row, lane, dv, sum); break;
+    case 5: sum = sdia_chunk<5, NT>(off, mask, vidx, cval, vp, x, d, row, lane, dv, sum); break;
+    case 4: sum = sdia_chunk<4, NT>(off, mask, vidx, cval, vp, x, d, row, lane, dv, sum); break;
+    case 3: sum = sdia_chunk<3, NT>(off, mask, vidx, cval, vp, x, d, row, lane, dv, sum); break;
+    case 2: sum = sdia_chunk<2, NT>(off, mask, vidx, cval, vp, x, d, row, lane, dv, sum); break;
+    case 1: sum = sdia_chunk<1, NT>(off, mask, vidx, cval, vp, x, d, row, lane, dv, sum); break;
+    default: break;
+    }
+    return sum;
+}
+
+// slice without any constant slot: its value blocks are consecutive, starting at block vidx[first slot]
+template <int L, bool NT>
+__device__ __forceinline__ double sdia_chunk_plain(const int *__restrict__ off, const unsigned long long *__restrict__ mask,
+                                                   const double *__restrict__ vp, const double *__restrict__ x, int d0, int row,
+                                                   int lane, double &dv, double sum)
 {
     double v[L], xv[L];
     bool on[L];
@@ -450,36 +504,160 @@ __device__ __forceinline__ double sdia_chunk(const int *__restrict__ off, const 
 }
 
 template <bool NT>
-__device__ __forceinline__ double sdia_row(const int *__restrict__ off, const unsigned long long *__restrict__ mask,
-                                           const double *__restrict__ vp, const double *__restrict__ x, int nd, int row, int lane,
-                                           double &dv)
+__device__ __forceinline__ double sdia_row_plain(const int *__restrict__ off, const unsigned long long *__restrict__ mask,
+                                                 const double *__restrict__ vp, const double *__restrict__ x, int nd, int row, int lane,
+                                                 double &dv)
 {
     double sum = 0.0;
     int d = 0;
-    for (; d + 8 <= nd; d += 8) sum = sdia_chunk<8, NT>(off, mask, vp, x, d, row, lane, dv, sum);
+    for (; d + 8 <= nd; d += 8) sum = sdia_chunk_plain<8, NT>(off, mask, vp, x, d, row, lane, dv, sum);
     switch (nd - d) {  // wave-uniform
-    case 7: sum = sdia_chunk<7, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
-    case 6: sum = sdia_chunk<6, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
-    case 5: sum = sdia_chunk<5, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
-    case 4: sum = sdia_chunk<4, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
-    case 3: sum = sdia_chunk<3, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
-    case 2: sum = sdia_chunk<2, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
-    case 1: sum = sdia_chunk<1, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    case 7: sum = sdia_chunk_plain<7, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    case 6: sum = sdia_chunk_plain<6, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    case 5: sum = sdia_chunk_plain<5, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    case 4: sum = sdia_chunk_plain<4, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    case 3: sum = sdia_chunk_plain<3, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    case 2: sum = sdia_chunk_plain<2, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
+    case 1: sum = sdia_chunk_plain<1, NT>(off, mask, vp, x, d, row, lane, dv, sum); break;
     default: break;
     }
     return sum;
 }
 
+// fully constant slice (every slot folded): no value stream at all.  Offsets, lane masks and the
+// slot constants are wave-uniform scalars; the lane mask is used directly as the lane predicate.
+template <int L>
+__device__ __forceinline__ double sdia_chunk_const(const int *__restrict__ off, const unsigned long long *__restrict__ mask,
+                                                   const double *__restrict__ cval, const double *__restrict__ x, int d0, int row,
+                                                   unsigned long long &dmask, double &dconst, double sum)
+{
+    double xv[L], cv[L];
+    bool on[L];
+#pragma unroll
+    for (int u = 0; u < L; ++u) {
+        const int o = __builtin_amdgcn_readfirstlane(off[d0 + u]);
+        const unsigned long long m = mask[d0 + u];     // wave-uniform
+        on[u] = __builtin_amdgcn_inverse_ballot_w64(m);  // bit i of the mask <-> lane i
+        cv[u] = cval[d0 + u];
+        if (o == 0) {  // the main diagonal's slot (scalar selects)
+            dmask = m;
+            dconst = cv[u];
+        }
+        xv[u] = x[on[u] ? row + o : row];  // clamp absent lanes onto a valid address
+    }
+#pragma unroll
+    for (int u = 0; u < L; ++u) {
+        const double t = cv[u] * xv[u];
+        sum = on[u] ? sum + t : sum;
+    }
+    return sum;
+}
+
+__device__ __forceinline__ double sdia_row_const(const int *__restrict__ off, const unsigned long long *__restrict__ mask,
+                                                 const double *__restrict__ cval, const double *__restrict__ x, int nd, int row,
+                                                 double &dv)
+{
+    double sum = 0.0;
+    unsigned long long dmask = 0ull;
+    double dconst = 0.0;
+    int d = 0;
+    for (; d + 8 <= nd; d += 8) sum = sdia_chunk_const<8>(off, mask, cval, x, d, row, dmask, dconst, sum);
+    switch (nd - d) {  // wave-uniform
+    case 7: sum = sdia_chunk_const<7>(off, mask, cval, x, d, row, dmask, dconst, sum); break;
+    case 6: sum = sdia_chunk_const<6>(off, mask, cval, x, d, row, dmask, dconst, sum); break;
+    case 5: sum = sdia_chunk_const<5>(off, mask, cval, x, d, row, dmask, dconst, sum); break;
+    case 4: sum = sdia_chunk_const<4>(off, mask, cval, x, d, row, dmask, dconst, sum); break;
+    case 3: sum = sdia_chunk_const<3>(off, mask, cval, x, d, row, dmask, dconst, sum); break;
+    case 2: sum = sdia_chunk_const<2>(off, mask, cval, x, d, row, dmask, dconst, sum); break;
+    case 1: sum = sdia_chunk_const<1>(off, mask, cval, x, d, row, dmask, dconst, sum); break;
+    default: break;
+    }
+    if (__builtin_amdgcn_inverse_ballot_w64(dmask)) dv = dconst;
+    return sum;
+}
+
+// record path: the whole slice description sits at rec (see DevCsr::sd_rec) and is fetched by one
+// batch of scalar loads before anything depends on it; count in 1..8
+struct SdRecord {
+    int off[8];
+    unsigned long long mask[8];
+    double cval[8];
+    int count;
+};
+
+__device__ __forceinline__ SdRecord load_sd_record(const int *__restrict__ rec)
+{
+    SdRecord r;
+    const unsigned long long *m = reinterpret_cast<const unsigned long long *>(rec + 8);
+    const double *c = reinterpret_cast<const double *>(rec + 24);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        r.off[u] = rec[u];
+        r.mask[u] = m[u];
+        r.cval[u] = c[u];
+    }
+    r.count = rec[40];
+    // keep the four scalar loads together ahead of the branch on count: without this the compiler
+    // sinks the three wide ones below that branch and the wave pays two dependent round trips
+    asm volatile("" ::"s"(r.count), "s"(r.off[0]), "s"(r.off[1]), "s"(r.off[2]), "s"(r.off[3]), "s"(r.off[4]), "s"(r.off[5]), "s"(r.off[6]),
+                 "s"(r.off[7]), "s"(r.mask[0]), "s"(r.mask[1]), "s"(r.mask[2]), "s"(r.mask[3]), "s"(r.mask[4]), "s"(r.mask[5]), "s"(r.mask[6]),
+                 "s"(r.mask[7]), "s"(r.cval[0]), "s"(r.cval[1]), "s"(r.cval[2]), "s"(r.cval[3]), "s"(r.cval[4]), "s"(r.cval[5]), "s"(r.cval[6]),
+                 "s"(r.cval[7]));
+    return r;
+}
+
+template <int L>
+__device__ __forceinline__ double sdia_rec_apply(const SdRecord &r, const double *__restrict__ x, int row, double &dv)
+{
+    double xv[L];
+    bool on[L];
+    unsigned long long dmask = 0ull;
+    double dconst = 0.0;
+#pragma unroll
+    for (int u = 0; u < L; ++u) {
+        on[u] = __builtin_amdgcn_inverse_ballot_w64(r.mask[u]);  // bit i of the mask <-> lane i
+        if (r.off[u] == 0) {  // the main diagonal's slot (scalar selects)
+            dmask = r.mask[u];
+            dconst = r.cval[u];
+        }
+        xv[u] = x[on[u] ? row + r.off[u] : row];  // clamp absent lanes onto a valid address
+    }
+    double sum = 0.0;
+#pragma unroll
+    for (int u = 0; u < L; ++u) {
+        const double t = r.cval[u] * xv[u];
+        sum = on[u] ? sum + t : sum;
+    }
+    if (__builtin_amdgcn_inverse_ballot_w64(dmask)) dv = dconst;
+    return sum;
+}
+
+__device__ __forceinline__ double sdia_row_rec(const SdRecord &r, const double *__restrict__ x, int row, double &dv)
+{
+    switch (r.count) {  // wave-uniform
+    case 8: return sdia_rec_apply<8>(r, x, row, dv);
+    case 7: return sdia_rec_apply<7>(r, x, row, dv);
+    case 6: return sdia_rec_apply<6>(r, x, row, dv);
+    case 5: return sdia_rec_apply<5>(r, x, row, dv);
+    case 4: return sdia_rec_apply<4>(r, x, row, dv);
+    case 3: return sdia_rec_apply<3>(r, x, row, dv);
+    case 2: return sdia_rec_apply<2>(r, x, row, dv);
+    case 1: return sdia_rec_apply<1>(r, x, row, dv);
+    default: return 0.0;
+    }
+}
+
 template <int OP, bool NT, int TAG>
 __global__ __launch_bounds__(kBlock) void sdia_kernel(int nrow, int nslice, int ngroups, int remap, const int *__restrict__ sd_ptr,
                                                        const int *__restrict__ sd_off, const unsigned long long *__restrict__ sd_mask,
-                                                       const double *__restrict__ sd_val, CsrArgs a)
+                                                       const int *__restrict__ sd_vidx, const double *__restrict__ sd_cval,
+                                                       const double *__restrict__ sd_val, const int *__restrict__ sd_rec, CsrArgs a)
 {
     __shared__ double red[kBlock / 64];
     const int gid = remap ? xcd_remap(blockIdx.x, ngroups, remap) : blockIdx.x;
     if (gid >= ngroups) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int idx = gid * (kBlock / 64) + w;
+    const int idx = __builtin_amdgcn_readfirstlane(gid * (kBlock / 64) + w);  // wave-uniform: keeps the slice metadata on the scalar path
     const int nwork = a.slice_list ? a.nlist : nslice;
     double acc = 0.0;
     if (idx < nwork) {
@@ -487,11 +665,30 @@ __global__ __launch_bounds__(kBlock) void sdia_kernel(int nrow, int nslice, int 
         int row = sl * 64 + lane;
         const bool has_row = row < nrow;
         if (!has_row) row = nrow - 1;  // tail lanes of the last slice: masks are clear, keep addresses valid
-        const int s0 = __builtin_amdgcn_readfirstlane(sd_ptr[sl]);
-        const int nd = __builtin_amdgcn_readfirstlane(sd_ptr[sl + 1]) - s0;
         RowOperands o;
         if (has_row) o = load_row_operands<OP, false>(a, row);
-        const double sum = sdia_row<NT>(sd_off + s0, sd_mask + s0, sd_val + (size_t)s0 * 64 + lane, a.x, nd, row, lane, o.di);
+        double sum;
+        bool done = false;
+        if (sd_rec) {  // value-free slices are described by fixed-stride records
+            const SdRecord r = load_sd_record(sd_rec + (size_t)sl * kSdRecInts);
+            if (r.count >= 0) {  // wave-uniform
+                sum = sdia_row_rec(r, a.x, row, o.di);
+                done = true;
+            }
+        }
+        if (!done) {
+            const int p0 = __builtin_amdgcn_readfirstlane(sd_ptr[sl]);
+            const int s0 = p0 & kSdPtrMask;
+            const int nd = (__builtin_amdgcn_readfirstlane(sd_ptr[sl + 1]) & kSdPtrMask) - s0;
+            if (p0 & kSdConstBit) {  // every slot of this slice is a constant slot (more than 8 of them)
+                sum = sdia_row_const(sd_off + s0, sd_mask + s0, sd_cval + s0, a.x, nd, row, o.di);
+            } else if (p0 & kSdPlainBit) {  // none is: consecutive value blocks, no per-slot indirection
+                const int v0 = __builtin_amdgcn_readfirstlane(sd_vidx[s0]);
+                sum = sdia_row_plain<NT>(sd_off + s0, sd_mask + s0, sd_val + (size_t)v0 * 64 + lane, a.x, nd, row, lane, o.di);
+            } else {
+                sum = sdia_row<NT>(sd_off + s0, sd_mask + s0, sd_vidx + s0, sd_cval + s0, sd_val + lane, a.x, nd, row, lane, o.di);
+            }
+        }
         if (has_row) acc = row_epilogue<OP>(a, row, sum, o);
     }
     if constexpr (op_reduces(OP)) {
@@ -544,8 +741,8 @@ __global__ __launch_bounds__(kBlock) void sdia_f32_kernel(int nrow, int nslice, 
     int row = sl * 64 + lane;
     const bool has_row = row < nrow;
     if (!has_row) row = nrow - 1;
-    const int s0 = __builtin_amdgcn_readfirstlane(sd_ptr[sl]);
-    const int nd = __builtin_amdgcn_readfirstlane(sd_ptr[sl + 1]) - s0;
+    const int s0 = __builtin_amdgcn_readfirstlane(sd_ptr[sl]) & kSdPtrMask;
+    const int nd = (__builtin_amdgcn_readfirstlane(sd_ptr[sl + 1]) & kSdPtrMask) - s0;
     const float bi = b[row];
     const float xi = (OP == OP_JACOBI) ? x[row] : 0.f;
     const int *off = sd_off + s0;
@@ -654,14 +851,14 @@ template <int OP, int TAG>
 int launch_csr_tagged(const DevCsr &A, const CsrArgs &a, bool nt, int remap, hipStream_t st)
 {
     const KernelConfig &c = g_cfg;
-    if (c.kind == 3 && A.sd_val) {
+    if (c.kind == 3 && A.has_sdia()) {
         const int ngroups = ((a.slice_list ? a.nlist : A.nslice) + 3) / 4;
         if (ngroups <= 0) return 0;
         const int grid = remap_grid(ngroups, remap);
         if (nt)
-            hipLaunchKernelGGL((sdia_kernel<OP, true, TAG>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.nslice, ngroups, remap, A.sd_ptr, A.sd_off, A.sd_mask, A.sd_val, a);
+            hipLaunchKernelGGL((sdia_kernel<OP, true, TAG>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.nslice, ngroups, remap, A.sd_ptr, A.sd_off, A.sd_mask, A.sd_vidx, A.sd_cval, A.sd_val, A.sd_rec, a);
         else
-            hipLaunchKernelGGL((sdia_kernel<OP, false, TAG>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.nslice, ngroups, remap, A.sd_ptr, A.sd_off, A.sd_mask, A.sd_val, a);
+            hipLaunchKernelGGL((sdia_kernel<OP, false, TAG>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.nslice, ngroups, remap, A.sd_ptr, A.sd_off, A.sd_mask, A.sd_vidx, A.sd_cval, A.sd_val, A.sd_rec, a);
         return ngroups;
     }
     if (c.kind >= 2 && A.sell_val) {
@@ -712,8 +909,8 @@ int launch_csr_op(const DevCsr &A, const CsrArgs &a, bool finest, hipStream_t st
         // default cache policy, one contiguous eighth of the rows per XCD.  If not: non-temporal
         // matrix stream and all XCDs sweeping one neighbourhood (groups of 16 row blocks).
         size_t bytes;
-        if (c.kind == 3 && A.sd_val)
-            bytes = (size_t)A.sd_slots * 64 * 8 + (size_t)A.nrow * 24;
+        if (c.kind == 3 && A.has_sdia())
+            bytes = (size_t)A.sd_vblocks * 64 * 8 + (A.sd_rec ? (size_t)A.nslice * kSdRecInts * 4 : (size_t)A.sd_slots * 24) + (size_t)A.nrow * 24;
         else if (c.kind >= 2 && A.sell_val)
             bytes = (size_t)A.sell_entries * 12 + (size_t)A.nrow * 28;
         else

@@ -32,11 +32,23 @@ struct DevCsr {
     // offsets (col - row) are stored once, values sit column-major by offset slot, a 64-bit lane
     // mask per slot says which rows really hold an entry there.  No per-entry column index: 8 B
     // instead of 12 B per stored entry.
-    int *sd_ptr = nullptr;              // nslice+1: first slot of every slice
+    int *sd_ptr = nullptr;              // nslice+1: first slot of every slice (| kSdConstBit, see below)
     int *sd_off = nullptr;              // per slot: col - row
     unsigned long long *sd_mask = nullptr;  // per slot: lanes (rows of the slice) that hold an entry
-    double *sd_val = nullptr;           // per slot: 64 values, lane-major
+    double *sd_val = nullptr;           // value blocks (64 values, lane-major) of the slots that need one
     long sd_slots = 0;
+    // constant slots: where every present entry of a slot carries the same value (constant-
+    // coefficient stencils and their aggregated coarse operators) the value lives once in sd_cval
+    // and the slot owns no block: sd_vidx = -1.  Otherwise sd_vidx = index of its block in sd_val.
+    int *sd_vidx = nullptr;
+    double *sd_cval = nullptr;
+    long sd_vblocks = 0;                // blocks stored in sd_val
+    // fixed-stride records (kSdRecInts ints per slice) for slices made of <= 8 constant slots: one
+    // address computation and one scalar round trip give the kernel everything it needs about the
+    // slice (offsets, lane masks, constants, slot count); other slices carry count -1 and go through
+    // sd_ptr.  Layout: int off[8]; u64 mask[8]; double cval[8]; int count; pad.
+    int *sd_rec = nullptr;
+    bool has_sdia() const { return sd_ptr != nullptr; }
     // rank-local blocks: slices whose rows touch no halo column (interior) / some (boundary)
     int *int_list = nullptr, *bnd_list = nullptr;
     int nint = 0, nbnd = 0;
@@ -50,12 +62,17 @@ struct KernelConfig {
     bool auto_policy = true;  // choose nt / remap per operator from its size (overrides the two below)
     bool nt = true;     // non-temporal loads for the matrix stream
     int remap = 1;      // 0 none, 1 XCD x owns the x-th contiguous eighth, G>1 groups of G row blocks dealt round-robin to XCDs
+    bool const_slots = true;  // layout option read at setup: fold constant diagonals of a slice into one scalar
 };
 KernelConfig &kernel_config();
 
 constexpr int kBlock = 256;       // threads per workgroup (4 waves)
 constexpr int kStreamNnz = 2048;  // products staged in LDS per workgroup (16 KiB)
 constexpr int kWaveNnz = 512;     // products staged in LDS per wave (4 KiB) in the wave-granular kernel
+constexpr int kSdRecInts = 48;        // 192 B per slice record
+constexpr int kSdConstBit = 1 << 30;  // set in sd_ptr[s] when every slot of slice s is a constant slot
+constexpr int kSdPlainBit = 1 << 29;  // set in sd_ptr[s] when no slot of slice s is (its value blocks are consecutive)
+constexpr int kSdPtrMask = (1 << 29) - 1;
 constexpr int kCsrPad = 4;        // zeroed entries appended to col/val so paired loads stay in bounds
 
 // epilogue selector of the CSR-stream kernel: what happens to the row sum s_i = (A x)_i

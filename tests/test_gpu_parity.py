@@ -312,3 +312,56 @@ def test_graph_replay_matches_eager():
     G.krylov_step_dev(4)
     hs = G.krylov_history()
     assert np.array_equal(hs, h0[:7])
+
+
+def _mixed_coefficients(n):
+    """5-pt stencil with a variable diagonal and a partly variable east coupling: slices hold constant
+    and non-constant diagonals side by side."""
+    rp, ci, v = problems.poisson2d(n)
+    rows = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
+    rng = np.random.default_rng(5)
+    v = v.copy()
+    diag = ci == rows
+    v[diag] += rng.random(int(diag.sum()))
+    east = (ci == rows + 1) & (rows < (len(rp) - 1) // 2)
+    v[east] = -0.5 - 0.25 * rng.random(int(east.sum()))
+    return rp, ci, v
+
+
+def test_constant_slot_folding_bitwise():
+    """Sliced-diagonal layout: slots whose entries share one value keep it as a scalar and own no value
+    block.  Folded, unfolded and oracle results must be bit-identical; the layout report must show the
+    folding (all slots on constant-coefficient Poisson, only some on the mixed operator)."""
+    rng = np.random.default_rng(23)
+    for name, (rp, ci, v) in (("p3d", problems.poisson3d(40)), ("mixed", _mixed_coefficients(200))):
+        n = len(rp) - 1
+        A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET, max_levels=2))
+        try:
+            sa.set_const_slots(False)
+            B = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET, max_levels=2))
+        finally:
+            sa.set_const_slots(True)
+        assert A.level_format(0)[0] == 3 and B.level_format(0)[0] == 3
+        sl, vb, _ = A.level_layout(0)
+        slb, vbb, _ = B.level_layout(0)
+        assert sl == slb and vbb == slb            # unfolded: one block per slot
+        if name == "p3d":
+            assert vb == 0                         # every diagonal of every slice is constant
+        else:
+            assert 0 < vb < sl                     # diagonal slots (and the upper-half east slots) keep blocks
+        O = oracle.Csr(rp, ci, v)
+        x = rng.standard_normal(n)
+        b = rng.standard_normal(n)
+        for nt, remap in ((1, 16), (0, 1), (-1, -1)):
+            sa.set_kernel_config(kind=3, vec=0, nt=nt, remap=remap)
+            try:
+                ya, yb = A.op_spmv(0, x), B.op_spmv(0, x)
+                assert np.array_equal(ya, yb) and np.array_equal(ya, oracle.spmv(O, x)), name
+                ja, jb = A.op_jacobi(0, b, x, 3), B.op_jacobi(0, b, x, 3)
+                assert np.array_equal(ja, jb) and np.array_equal(ja, oracle.jacobi(O, b, x, 2)), name
+                assert np.array_equal(A.op_residual(0, b, x), oracle.store_residual(O, b, x)), name
+                assert A.op_resnorm(0, b, x) == B.op_resnorm(0, b, x)
+            finally:
+                sa.set_kernel_config()
+        A.close()
+        B.close()

@@ -25,7 +25,11 @@ def main():
     ap.add_argument("--variants", action="store_true", help="A/B all kernel families (interleaved rounds, one process)")
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--vlevels", type=int, nargs="*", default=[0, 2, 4])
+    ap.add_argument("--no-const", action="store_true", help="build the sliced-diagonal layout without constant-slot folding")
+    ap.add_argument("--kinds", type=int, nargs="*", default=[3, 2], help="kernel families of the --remaps sweep")
     a = ap.parse_args()
+    if a.no_const:
+        sa.set_const_slots(False)
     if a.fem:
         rp, ci, v = problems.fem_unstructured(a.fem, ordering=a.ordering)
     else:
@@ -36,7 +40,7 @@ def main():
     if a.remaps:
         print(f"{'config':28s} {'op':8s} {'lvl':>3s} {'us':>9s} {'GB/s':>8s} {'frac8T':>7s}")
         for rnd in range(a.rounds):
-            for (k, v) in ((3, 0), (2, 0)):
+            for (k, v) in [(kk, 0) for kk in a.kinds]:
                 for nt in (1, 0):
                     for rm in a.remaps:
                         sa.set_kernel_config(kind=k, vec=v, nt=nt, remap=rm)
@@ -68,6 +72,7 @@ def main():
         sa.set_kernel_config()
         return
     print("level formats (3 sliced diagonals, 2 sliced ELL, 0 CSR-stream):", [A.level_format(l)[0] for l in range(A.nlevels)])
+    print("sliced-diagonal slots / value blocks per level:", [A.level_layout(l) for l in range(A.nlevels)])
     print(f"{'op':10s} {'lvl':>3s} {'rows':>10s} {'nnz':>10s} {'us':>9s} {'GB/s':>8s} {'frac8T':>7s}")
     for l in range(min(a.levels, A.nlevels)):
         i = A.level_info(l)

@@ -31,8 +31,16 @@ def run():
 
     rp, ci, v = problems.poisson3d(N_GRID)
     A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, print_solve=0))
+    cfg = os.environ.get("SPARSH_PMC_CFG")  # "kind,vec,nt,remap": override the per-operator policy (diagnostics)
+    if cfg:
+        sa.set_kernel_config(*[int(t) for t in cfg.split(",")])
     for op in ("axpby", "dot", "copy_int", "jacobi"):
         A.bench_op(op, 0, 4)
+    slots, vblocks, meta = A.level_layout(0)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "pmc_layout.json"), "w") as f:
+        json.dump({"slots": slots, "value_blocks": vblocks, "descriptor_bytes": meta}, f)
 
 
 def collect(d):
@@ -71,12 +79,20 @@ def summarize(fetch_dir, write_dir, out_path):
     # diagonals: no per-entry index (offsets/masks are per slot: < 1.5 % of the bytes, counted with
     # the 8-byte streams).  raw = bytes4/f4 + bytes8/f8  ->  solve for bytes8.
     pad_nnz = 7 * n
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lay_path = os.path.join(root, "gpurun_out", "pmc_layout.json")
+    layout = json.load(open(lay_path)) if os.path.exists(lay_path) else None
     kind = int(fetch.pop("_kind", 2.0))
     cnt.pop("_kind", None)
     bytes4 = (4 * pad_nnz + 4 * n) if kind == 2 else 0
     bytes8 = (fetch["jacobi"] - bytes4 / f4) * f8
     read_total = bytes4 + bytes8
-    nstream8 = 8 * pad_nnz + (16 * n if kind == 2 else 8 * n)  # values + b (+ d for ELL before the diagonal pick-up)
+    # bytes of the value stream: sliced diagonals store 64-value blocks only for non-constant slots
+    val_bytes = 8 * pad_nnz
+    meta_bytes = 0
+    if kind == 3 and layout is not None:
+        val_bytes = 512 * layout["value_blocks"]
+        meta_bytes = layout.get("descriptor_bytes", 24 * layout["slots"])
     alg = 12 * nnz + 36 * n
     res = {
         "_how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); counter KiB -> bytes; per-width correction from "
@@ -90,7 +106,8 @@ def summarize(fetch_dir, write_dir, out_path):
         "jacobi_fine_algorithmic_bytes": alg,
         "ratio_traffic_over_algorithmic": (read_total + write["jacobi"] * wf8) / alg,
         "kernel_family": {3: "sdia_kernel (sliced diagonals)", 2: "sell_kernel (sliced ELL)", 0: "csr_block_kernel"}.get(kind),
-        "x_vector_fetches_per_entry": (bytes8 - 8 * pad_nnz - 8 * n) / (8 * n),
+        "layout": layout,
+        "x_vector_fetches_per_entry": (bytes8 - val_bytes - meta_bytes - 8 * n) / (8 * n),
     }
     with open(out_path, "w") as f:
         json.dump(res, f, indent=1)
