@@ -87,6 +87,8 @@ def main():
     import sparsh_amg_amd as sa
     from sparsh_amg_amd import problems
 
+    if os.environ.get("SPARSH_BENCH_KCFG"):  # A/B runs: "kind,vec,nt,remap" instead of the per-operator policy
+        sa.set_kernel_config(*[int(t) for t in os.environ["SPARSH_BENCH_KCFG"].split(",")])
     if sa.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the HIP path is the only compute path")
 
@@ -214,7 +216,7 @@ def main():
     pr = A.profile_read()
     jac_bytes = 12 * pr["nnz"] + 36 * pr["nrow"]  # SURVEY §8d CSR model, this rank's block of the finest level
     fmt, stored = A.level_format(0)
-    fmt_name = {3: "sdia_kernel", 2: "sell_kernel", 1: "csr_wave_kernel", 0: "csr_block_kernel"}[fmt]
+    fmt_name = A.level_kernel(0)
     # bytes the chosen layout really has to move per sweep: values (+ column indices unless the
     # layout stores diagonals), b, x_i / gathered x once, x_new; the diagonal comes out of the
     # value stream for the mirrors

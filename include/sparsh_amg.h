@@ -116,12 +116,17 @@ int sparsh_level_format(sparsh_handle h, int level, int *kind, long *stored_entr
  * constant-coefficient stencils and their aggregated coarse operators) keeps that value once in
  * its header and owns no block; the arithmetic is unchanged (same products, same order).  Slices
  * made of at most 8 constant slots are described by one fixed-stride 192-byte record (offsets,
- * lane masks, constants, count) the kernel fetches with a single batch of scalar loads.
+ * lane masks, constants, count) the kernel fetches with a single batch of scalar loads; when
+ * (nearly) all of them draw their (offset, constant) pairs from one set of at most 8, that set
+ * travels as a kernel argument and a slice only needs its 8 lane masks (64 B).
  * meta_bytes = bytes of slice/slot descriptors one sweep reads.  All 0 when the level does not use
  * the layout.  sparsh_set_const_slots(0) before sparsh_setup turns the folding off (A/B
  * measurements; default on). */
 int sparsh_level_layout(sparsh_handle h, int level, long *slots, long *value_blocks, long *meta_bytes);
 int sparsh_set_const_slots(int enable);
+/* name of the kernel the SpMV-type operations of a level launch under the current config
+ * ("sdia_tab_kernel", "sdia_kernel", "sell_kernel", "csr_wave_kernel", "csr_block_kernel") */
+const char *sparsh_level_kernel(sparsh_handle h, int level);
 
 /* Host half of sparsh_setup only (coarsening, Galerkin products, coarse factorisation); needs
  * no GPU.  Enables the inspection calls below; solvers still require sparsh_setup. */

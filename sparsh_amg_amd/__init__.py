@@ -84,6 +84,7 @@ def _load():
         "sparsh_level_format": (C.c_int, [H, C.c_int, c_int_p, C.POINTER(C.c_long)]),
         "sparsh_level_layout": (C.c_int, [H, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
         "sparsh_set_const_slots": (C.c_int, [C.c_int]),
+        "sparsh_level_kernel": (C.c_char_p, [H, C.c_int]),
         "sparsh_num_levels": (C.c_int, [H]),
         "sparsh_level_info": (C.c_int, [H, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p]),
         "sparsh_level_csr": (C.c_int, [H, C.c_int, C.c_int, c_int_p, c_int_p, c_dbl_p]),
@@ -261,6 +262,10 @@ class sp_matrix_mg:
         k, e = C.c_int(), C.c_long()
         _check(lib.sparsh_level_format(self._h, level, C.byref(k), C.byref(e)))
         return k.value, e.value
+
+    def level_kernel(self, level):
+        """Name of the kernel the SpMV-type operations of this level launch under the current config."""
+        return lib.sparsh_level_kernel(self._h, level).decode()
 
     def level_layout(self, level):
         """(slots, value blocks, descriptor bytes) of the sliced-diagonal layout of this level; constant

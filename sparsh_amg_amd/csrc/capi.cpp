@@ -215,12 +215,24 @@ int sparsh_level_layout(sparsh_handle h, int level, long *slots, long *value_blo
         // only when there are no records), else sd_ptr + 24 B per slot
         if (!A.has_sdia())
             *meta_bytes = 0;
+        else if (A.sd_tmask)  // table path: 8 lane masks + the conformity word per slice
+            *meta_bytes = (long)A.nslice * 68 + A.sd_vblocks * 24;
         else if (A.sd_rec)
             *meta_bytes = (long)A.nslice * kSdRecInts * 4 + A.sd_vblocks * 24;
         else
             *meta_bytes = (long)A.nslice * 4 + A.sd_slots * 24;
     }
     return SPARSH_OK;
+}
+
+const char *sparsh_level_kernel(sparsh_handle h, int level)
+{
+    if (!h || !h->eng || !h->eng->ready() || level < 0 || level >= (int)h->eng->host().levels.size()) return "";
+    const DevCsr &A = h->eng->level(level).A;
+    const KernelConfig &c = kernel_config();
+    if (c.kind == 3 && A.has_sdia()) return (c.table && A.sd_tmask) ? "sdia_tab_kernel" : "sdia_kernel";
+    if (c.kind >= 2 && A.sell_val) return "sell_kernel";
+    return c.kind == 1 ? "csr_wave_kernel" : "csr_block_kernel";
 }
 
 int sparsh_set_const_slots(int enable)

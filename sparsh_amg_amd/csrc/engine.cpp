@@ -268,6 +268,69 @@ bool upload_sdia(Engine &E, const HostCsr &A, DevCsr &D)
         D.sd_rec = upload(E, rec.data(), rec.size());
         if (!D.sd_rec) return false;
     }
+    // level-wide stencil table (see DevCsr::sd_tab): the most frequent full signature among the
+    // value-free slices; a slice conforms when each of its slots is a (offset, constant) of the table
+    if (with_rec) {
+        auto sig_less = [&](int sa, int sb) {  // order slices by (count, offsets, constants)
+            const int *ra = &rec[(size_t)sa * kSdRecInts], *rb = &rec[(size_t)sb * kSdRecInts];
+            if (ra[40] != rb[40]) return ra[40] < rb[40];
+            const int c = std::memcmp(ra, rb, 8 * sizeof(int));
+            if (c) return c < 0;
+            return std::memcmp(ra + 24, rb + 24, 8 * sizeof(double)) < 0;
+        };
+        auto sig_eq = [&](int sa, int sb) { return !sig_less(sa, sb) && !sig_less(sb, sa); };
+        std::vector<int> cand;
+        for (int sl = 0; sl < nslice; ++sl)
+            if (rec[(size_t)sl * kSdRecInts + 40] > 0) cand.push_back(sl);
+        if (!cand.empty()) {
+            std::sort(cand.begin(), cand.end(), sig_less);
+            int best_sl = -1;
+            long best = 0;
+            for (size_t i = 0; i < cand.size();) {
+                size_t j = i;
+                while (j < cand.size() && sig_eq(cand[i], cand[j])) ++j;
+                if ((long)(j - i) > best) {
+                    best = (long)(j - i);
+                    best_sl = cand[i];
+                }
+                i = j;
+            }
+            SdTable tab;
+            const int *rb = &rec[(size_t)best_sl * kSdRecInts];
+            tab.nd = rb[40];
+            for (int u = 0; u < tab.nd; ++u) {
+                tab.off[u] = rb[u];
+                std::memcpy(&tab.cval[u], &rb[24 + 2 * u], 8);
+            }
+            std::vector<unsigned long long> tmask((size_t)nslice * 8, 0ull);
+            std::vector<int> tconf((size_t)nslice, 0);
+            long nconf = 0;
+#pragma omp parallel for schedule(static) reduction(+ : nconf)
+            for (int sl = 0; sl < nslice; ++sl) {
+                const int *r = &rec[(size_t)sl * kSdRecInts];
+                if (r[40] <= 0) continue;
+                bool ok = true;
+                unsigned long long mm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int q = 0; q < r[40] && ok; ++q) {
+                    int hit = -1;
+                    for (int u = 0; u < tab.nd; ++u)
+                        if (tab.off[u] == r[q] && std::memcmp(&tab.cval[u], &r[24 + 2 * q], 8) == 0) hit = u;
+                    if (hit < 0) ok = false;
+                    else std::memcpy(&mm[hit], &r[8 + 2 * q], 8);
+                }
+                if (!ok) continue;
+                for (int u = 0; u < 8; ++u) tmask[(size_t)sl * 8 + u] = mm[u];
+                tconf[(size_t)sl] = 1;
+                ++nconf;
+            }
+            if (nconf * 10 >= (long)nslice * 9) {  // worth a launch-wide assumption only if it nearly always holds
+                D.sd_tab = tab;
+                D.sd_tmask = upload(E, tmask.data(), tmask.size());
+                D.sd_tconf = upload(E, tconf.data(), tconf.size());
+                if (!D.sd_tmask || !D.sd_tconf) return false;
+            }
+        }
+    }
     D.sd_ptr = upload(E, sp.data(), sp.size());
     D.sd_off = upload(E, off.data(), off.size());
     D.sd_mask = upload(E, mask.data(), mask.size());
@@ -290,8 +353,19 @@ bool upload_csr(Engine &E, const HostCsr &A, DevCsr &D, bool with_sell)
     D.rowblk = upload(E, rb.data(), (size_t)D.nblk + 1);
     D.nwblk = build_waveblocks(A.nrow, A.rowptr, rb.data());
     D.waveblk = upload(E, rb.data(), (size_t)D.nwblk + 1);
-    if (with_sell && (!upload_sell(E, A, D) || !upload_sdia(E, A, D))) return false;
-    return D.rowptr && D.col && D.val && D.rowblk && D.waveblk;
+    if (with_sell && !upload_sell(E, A, D)) {
+        if (E.error.empty()) E.error = "building the sliced-ELL mirror failed";
+        return false;
+    }
+    if (with_sell && !upload_sdia(E, A, D)) {
+        if (E.error.empty()) E.error = "building the sliced-diagonal mirror failed";
+        return false;
+    }
+    if (!(D.rowptr && D.col && D.val && D.rowblk && D.waveblk)) {
+        if (E.error.empty()) E.error = "uploading a CSR operator failed";
+        return false;
+    }
+    return true;
 }
 
 int partial_count(const DevCsr &D) { return std::max(D.nblk, std::max((D.nwblk + 3) / 4, (D.nslice + 3) / 4)); }

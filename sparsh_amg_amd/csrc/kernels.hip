@@ -697,6 +697,108 @@ __global__ __launch_bounds__(kBlock) void sdia_kernel(int nrow, int nslice, int 
     }
 }
 
+// Table path (DevCsr::sd_tab): offsets and constants are kernel arguments, so the x gathers leave
+// at once (out-of-range rows clamped; lanes without the entry are dropped by the mask afterwards).
+template <int L>
+__device__ __forceinline__ double sdia_tab_apply(const SdTable &tab, const unsigned long long *__restrict__ mrec, const double *__restrict__ x,
+                                                 int row, int xlen, double &dv, bool &conform, const int *__restrict__ conf_ptr)
+{
+    double xv[L];
+#pragma unroll
+    for (int u = 0; u < L; ++u) {
+        const int idx = row + tab.off[u];
+        xv[u] = x[(unsigned)idx < (unsigned)xlen ? idx : row];  // xlen = entries of x (own + halo on a rank-local block)
+    }
+    unsigned long long m[L];
+#pragma unroll
+    for (int u = 0; u < L; ++u) m[u] = mrec[u];  // wave-uniform: scalar loads, issued beside the gathers
+    conform = __builtin_amdgcn_readfirstlane(*conf_ptr) != 0;
+    double sum = 0.0;
+    unsigned long long dmask = 0ull;
+    double dconst = 0.0;
+#pragma unroll
+    for (int u = 0; u < L; ++u) {
+        const bool on = __builtin_amdgcn_inverse_ballot_w64(m[u]);
+        if (tab.off[u] == 0) {
+            dmask = m[u];
+            dconst = tab.cval[u];
+        }
+        const double t = tab.cval[u] * xv[u];
+        sum = on ? sum + t : sum;
+    }
+    if (__builtin_amdgcn_inverse_ballot_w64(dmask)) dv = dconst;
+    return sum;
+}
+
+template <int OP, bool NT, int TAG>
+__global__ __launch_bounds__(kBlock) void sdia_tab_kernel(int nrow, int xlen, int nslice, int ngroups, int remap, SdTable tab,
+                                                           const unsigned long long *__restrict__ sd_tmask, const int *__restrict__ sd_tconf,
+                                                           const int *__restrict__ sd_ptr, const int *__restrict__ sd_off,
+                                                           const unsigned long long *__restrict__ sd_mask, const int *__restrict__ sd_vidx,
+                                                           const double *__restrict__ sd_cval, const double *__restrict__ sd_val,
+                                                           const int *__restrict__ sd_rec, CsrArgs a)
+{
+    __shared__ double red[kBlock / 64];
+    const int gid = remap ? xcd_remap(blockIdx.x, ngroups, remap) : blockIdx.x;
+    if (gid >= ngroups) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int idx = __builtin_amdgcn_readfirstlane(gid * (kBlock / 64) + w);
+    double acc = 0.0;
+    if (idx < nslice) {
+        const int sl = idx;
+        int row = sl * 64 + lane;
+        const bool has_row = row < nrow;
+        if (!has_row) row = nrow - 1;
+        RowOperands o;
+        if (has_row) o = load_row_operands<OP, false>(a, row);
+        const unsigned long long *mrec = sd_tmask + (size_t)sl * 8;
+        const int *cp = sd_tconf + sl;
+        bool conform = false;
+        double sum = 0.0;
+        double dv = o.di;
+        switch (tab.nd) {  // uniform over the whole launch
+        case 8: sum = sdia_tab_apply<8>(tab, mrec, a.x, row, xlen, dv, conform, cp); break;
+        case 7: sum = sdia_tab_apply<7>(tab, mrec, a.x, row, xlen, dv, conform, cp); break;
+        case 6: sum = sdia_tab_apply<6>(tab, mrec, a.x, row, xlen, dv, conform, cp); break;
+        case 5: sum = sdia_tab_apply<5>(tab, mrec, a.x, row, xlen, dv, conform, cp); break;
+        case 4: sum = sdia_tab_apply<4>(tab, mrec, a.x, row, xlen, dv, conform, cp); break;
+        case 3: sum = sdia_tab_apply<3>(tab, mrec, a.x, row, xlen, dv, conform, cp); break;
+        case 2: sum = sdia_tab_apply<2>(tab, mrec, a.x, row, xlen, dv, conform, cp); break;
+        default: sum = sdia_tab_apply<1>(tab, mrec, a.x, row, xlen, dv, conform, cp); break;
+        }
+        if (conform) {
+            o.di = dv;
+        } else {  // rare: a slice off the level's stencil goes through its record / slot headers
+            bool done = false;
+            if (sd_rec) {
+                const SdRecord r = load_sd_record(sd_rec + (size_t)sl * kSdRecInts);
+                if (r.count >= 0) {
+                    sum = sdia_row_rec(r, a.x, row, o.di);
+                    done = true;
+                }
+            }
+            if (!done) {
+                const int p0 = __builtin_amdgcn_readfirstlane(sd_ptr[sl]);
+                const int s0 = p0 & kSdPtrMask;
+                const int nd = (__builtin_amdgcn_readfirstlane(sd_ptr[sl + 1]) & kSdPtrMask) - s0;
+                if (p0 & kSdConstBit) {
+                    sum = sdia_row_const(sd_off + s0, sd_mask + s0, sd_cval + s0, a.x, nd, row, o.di);
+                } else if (p0 & kSdPlainBit) {
+                    const int v0 = __builtin_amdgcn_readfirstlane(sd_vidx[s0]);
+                    sum = sdia_row_plain<NT>(sd_off + s0, sd_mask + s0, sd_val + (size_t)v0 * 64 + lane, a.x, nd, row, lane, o.di);
+                } else {
+                    sum = sdia_row<NT>(sd_off + s0, sd_mask + s0, sd_vidx + s0, sd_cval + s0, sd_val + lane, a.x, nd, row, lane, o.di);
+                }
+            }
+        }
+        if (has_row) acc = row_epilogue<OP>(a, row, sum, o);
+    }
+    if constexpr (op_reduces(OP)) {
+        const double t = block_sum(acc, red);
+        if (threadIdx.x == 0) a.partial[a.partial_off + gid] = t;
+    }
+}
+
 // ------------------------------------------------------------------ fp32 preconditioner kernels
 // Same sliced-diagonal structure with float values and float vectors: 4 B per stored entry and
 // 12 B per row for a fused sweep.  Used only inside the (opt-in) fp32 V-cycle; the fp64 parity
@@ -851,6 +953,15 @@ template <int OP, int TAG>
 int launch_csr_tagged(const DevCsr &A, const CsrArgs &a, bool nt, int remap, hipStream_t st)
 {
     const KernelConfig &c = g_cfg;
+    if (c.kind == 3 && A.has_sdia() && c.table && A.sd_tmask && !a.slice_list) {
+        const int ngroups = (A.nslice + 3) / 4;
+        const int grid = remap_grid(ngroups, remap);
+        if (nt)
+            hipLaunchKernelGGL((sdia_tab_kernel<OP, true, TAG>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.ncol, A.nslice, ngroups, remap, A.sd_tab, A.sd_tmask, A.sd_tconf, A.sd_ptr, A.sd_off, A.sd_mask, A.sd_vidx, A.sd_cval, A.sd_val, A.sd_rec, a);
+        else
+            hipLaunchKernelGGL((sdia_tab_kernel<OP, false, TAG>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.ncol, A.nslice, ngroups, remap, A.sd_tab, A.sd_tmask, A.sd_tconf, A.sd_ptr, A.sd_off, A.sd_mask, A.sd_vidx, A.sd_cval, A.sd_val, A.sd_rec, a);
+        return ngroups;
+    }
     if (c.kind == 3 && A.has_sdia()) {
         const int ngroups = ((a.slice_list ? a.nlist : A.nslice) + 3) / 4;
         if (ngroups <= 0) return 0;
@@ -910,7 +1021,8 @@ int launch_csr_op(const DevCsr &A, const CsrArgs &a, bool finest, hipStream_t st
         // matrix stream and all XCDs sweeping one neighbourhood (groups of 16 row blocks).
         size_t bytes;
         if (c.kind == 3 && A.has_sdia())
-            bytes = (size_t)A.sd_vblocks * 64 * 8 + (A.sd_rec ? (size_t)A.nslice * kSdRecInts * 4 : (size_t)A.sd_slots * 24) + (size_t)A.nrow * 24;
+            bytes = (size_t)A.sd_vblocks * 64 * 8 + (size_t)A.nrow * 24 +
+                    (A.sd_tmask ? (size_t)A.nslice * 68 : (A.sd_rec ? (size_t)A.nslice * kSdRecInts * 4 : (size_t)A.sd_slots * 24));
         else if (c.kind >= 2 && A.sell_val)
             bytes = (size_t)A.sell_entries * 12 + (size_t)A.nrow * 28;
         else

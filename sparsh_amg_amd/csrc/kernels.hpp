@@ -7,6 +7,13 @@
 
 namespace sparsh {
 
+// level-wide stencil of the sliced-diagonal layout (see DevCsr::sd_tab)
+struct SdTable {
+    int nd = 0;
+    int off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double cval[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
 // Device CSR + the row-block schedule of the CSR-stream kernels.
 struct DevCsr {
     int nrow = 0, ncol = 0, nnz = 0;
@@ -48,6 +55,14 @@ struct DevCsr {
     // slice (offsets, lane masks, constants, slot count); other slices carry count -1 and go through
     // sd_ptr.  Layout: int off[8]; u64 mask[8]; double cval[8]; int count; pad.
     int *sd_rec = nullptr;
+    // level-wide stencil table: when (nearly) all value-free slices draw their (offset, constant)
+    // pairs from one set of <= 8, that set travels as a kernel argument and a slice only needs its
+    // 8 lane masks (sd_tmask, 64 B per slice; sd_tconf = 1 where the slice conforms).  The wave then
+    // issues its x gathers straight from the kernel arguments, in parallel with the mask load,
+    // instead of after a record round trip.
+    SdTable sd_tab;
+    unsigned long long *sd_tmask = nullptr;
+    int *sd_tconf = nullptr;
     bool has_sdia() const { return sd_ptr != nullptr; }
     // rank-local blocks: slices whose rows touch no halo column (interior) / some (boundary)
     int *int_list = nullptr, *bnd_list = nullptr;
@@ -62,6 +77,7 @@ struct KernelConfig {
     bool auto_policy = true;  // choose nt / remap per operator from its size (overrides the two below)
     bool nt = true;     // non-temporal loads for the matrix stream
     int remap = 1;      // 0 none, 1 XCD x owns the x-th contiguous eighth, G>1 groups of G row blocks dealt round-robin to XCDs
+    bool table = true;  // use the level-wide stencil table where a level has one
     bool const_slots = true;  // layout option read at setup: fold constant diagonals of a slice into one scalar
 };
 KernelConfig &kernel_config();

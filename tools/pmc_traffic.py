@@ -55,9 +55,10 @@ def collect(d):
             key = "dot"
         elif "copy_int_kernel" in name:
             key = "copy_int"
-        elif ("sdia_kernel<2" in name or "sell_kernel<2" in name or "csr_block_kernel<2" in name) and ", 1>" in name:
+        elif ("sdia_kernel<2" in name or "sdia_tab_kernel<2" in name or "sdia_ord_kernel<2" in name or "sell_kernel<2" in name
+              or "csr_block_kernel<2" in name) and ", 1>" in name:
             key = "jacobi"
-            out["_kind"] = [3.0 if "sdia_kernel" in name else (2.0 if "sell_kernel" in name else 0.0)]
+            out["_kind"] = [3.0 if "sdia_" in name else (2.0 if "sell_kernel" in name else 0.0)]
         if key:
             out.setdefault(key, []).append(float(r["Counter_Value"]) * 1024.0)
     return {k: sum(v) / len(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
