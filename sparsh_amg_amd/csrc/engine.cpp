@@ -302,6 +302,11 @@ bool upload_sdia(Engine &E, const HostCsr &A, DevCsr &D)
                 tab.off[u] = rb[u];
                 std::memcpy(&tab.cval[u], &rb[24 + 2 * u], 8);
             }
+            {
+                const int c0 = tab.nd / 2;
+                if ((tab.nd == 7 || tab.nd == 5 || tab.nd == 3) && tab.off[c0] == 0 && tab.off[c0 - 1] == -1 && tab.off[c0 + 1] == 1)
+                    tab.near = tab.nd * 10 + c0;
+            }
             std::vector<unsigned long long> tmask((size_t)nslice * 8, 0ull);
             std::vector<int> tconf((size_t)nslice, 0);
             long nconf = 0;

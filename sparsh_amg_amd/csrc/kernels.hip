@@ -110,14 +110,14 @@ struct RowOperands {
 
 // LOAD_D = false: the kernel picks the diagonal out of the matrix stream it reads anyway (the
 // entry with col == row; same value as diag[], src/AMG_cpu_matrix.cpp:35-51) and skips the 8 B/row
-template <int OP, bool LOAD_D = true>
+template <int OP, bool LOAD_D = true, bool LOAD_XI = true>
 __device__ __forceinline__ RowOperands load_row_operands(const CsrArgs &a, int row)
 {
     RowOperands o;
     if constexpr (op_needs_b(OP)) o.bi = a.b[row];
     if constexpr (op_needs_d(OP) && LOAD_D) o.di = a.d[row];
     if constexpr (op_needs_d(OP) && !LOAD_D) o.di = 0.0;  // a row without a diagonal entry keeps diag[] = 0
-    if constexpr (op_needs_xi(OP)) o.xi = a.x[row];
+    if constexpr (op_needs_xi(OP) && LOAD_XI) o.xi = a.x[row];
     return o;
 }
 
@@ -730,6 +730,60 @@ __device__ __forceinline__ double sdia_tab_apply(const SdTable &tab, const unsig
     return sum;
 }
 
+// value of lane-1 / lane+1 across the whole wave (DPP wave shifts); `edge` fills the lane that has
+// no neighbour (lane 0 resp. lane 63)
+__device__ __forceinline__ double lane_from_below(double v, double edge)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_from_above(double v, double edge)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Table path for stencils whose offsets -1, 0, +1 sit in slots C0-1, C0, C0+1 (every grid stencil in
+// lexicographic order).  The kernel is bound by the number of wave-level memory instructions
+// (profiles/r01_band_experiment_vmem_bound.txt: ~2.7 us per gather at 216^3 whether it hits L1 or
+// not), so the three gathers of x[r-1], x[r], x[r+1] become ONE: the neighbours come from the lanes
+// next door by DPP, the two values beyond the slice's ends by scalar loads; x_i for the Jacobi /
+// dot epilogues is that same centre value instead of a load of its own.
+template <int L, int C0>
+__device__ __forceinline__ double sdia_tab_apply_near(const SdTable &tab, const unsigned long long *__restrict__ mrec,
+                                                      const double *__restrict__ x, int row, int row0, int xlen, double &dv, double &xc,
+                                                      bool &conform, const int *__restrict__ conf_ptr)
+{
+    double xv[L];
+#pragma unroll
+    for (int u = 0; u < L; ++u) {
+        if (u == C0 - 1 || u == C0 + 1) continue;
+        const int idx = row + tab.off[u];
+        xv[u] = x[(unsigned)idx < (unsigned)xlen ? idx : row];
+    }
+    // beyond the slice's ends (wave-uniform addresses; clamped, the masks drop what does not exist)
+    const double below = x[row0 > 0 ? row0 - 1 : 0];
+    const double above = x[row0 + 64 < xlen ? row0 + 64 : xlen - 1];
+    unsigned long long m[L];
+#pragma unroll
+    for (int u = 0; u < L; ++u) m[u] = mrec[u];  // wave-uniform: scalar loads, issued beside the gathers
+    conform = __builtin_amdgcn_readfirstlane(*conf_ptr) != 0;
+    xc = xv[C0];
+    xv[C0 - 1] = lane_from_below(xv[C0], below);
+    xv[C0 + 1] = lane_from_above(xv[C0], above);
+    double sum = 0.0;
+#pragma unroll
+    for (int u = 0; u < L; ++u) {
+        const bool on = __builtin_amdgcn_inverse_ballot_w64(m[u]);
+        const double t = tab.cval[u] * xv[u];
+        sum = on ? sum + t : sum;
+    }
+    if (__builtin_amdgcn_inverse_ballot_w64(m[C0])) dv = tab.cval[C0];
+    return sum;
+}
+
 template <int OP, bool NT, int TAG>
 __global__ __launch_bounds__(kBlock) void sdia_tab_kernel(int nrow, int xlen, int nslice, int ngroups, int remap, SdTable tab,
                                                            const unsigned long long *__restrict__ sd_tmask, const int *__restrict__ sd_tconf,
@@ -749,13 +803,24 @@ __global__ __launch_bounds__(kBlock) void sdia_tab_kernel(int nrow, int xlen, in
         int row = sl * 64 + lane;
         const bool has_row = row < nrow;
         if (!has_row) row = nrow - 1;
-        RowOperands o;
-        if (has_row) o = load_row_operands<OP, false>(a, row);
         const unsigned long long *mrec = sd_tmask + (size_t)sl * 8;
         const int *cp = sd_tconf + sl;
         bool conform = false;
         double sum = 0.0;
-        double dv = o.di;
+        RowOperands o;
+        double dv = 0.0;
+        // lexicographic grid stencils: -1, 0, +1 in adjacent slots (launch-uniform test on kernel arguments)
+        const int near = tab.near;
+        if (near) {
+            if (has_row) o = load_row_operands<OP, false, false>(a, row);  // x_i comes with the centre gather
+            double xc = 0.0;
+            if (near == 73) sum = sdia_tab_apply_near<7, 3>(tab, mrec, a.x, row, sl * 64, xlen, dv, xc, conform, cp);
+            else if (near == 52) sum = sdia_tab_apply_near<5, 2>(tab, mrec, a.x, row, sl * 64, xlen, dv, xc, conform, cp);
+            else sum = sdia_tab_apply_near<3, 1>(tab, mrec, a.x, row, sl * 64, xlen, dv, xc, conform, cp);
+            if constexpr (op_needs_xi(OP)) o.xi = xc;
+        } else {
+        if (has_row) o = load_row_operands<OP, false>(a, row);
+        dv = o.di;
         switch (tab.nd) {  // uniform over the whole launch
         case 8: sum = sdia_tab_apply<8>(tab, mrec, a.x, row, xlen, dv, conform, cp); break;
         case 7: sum = sdia_tab_apply<7>(tab, mrec, a.x, row, xlen, dv, conform, cp); break;
@@ -766,9 +831,11 @@ __global__ __launch_bounds__(kBlock) void sdia_tab_kernel(int nrow, int xlen, in
         case 2: sum = sdia_tab_apply<2>(tab, mrec, a.x, row, xlen, dv, conform, cp); break;
         default: sum = sdia_tab_apply<1>(tab, mrec, a.x, row, xlen, dv, conform, cp); break;
         }
+        }
         if (conform) {
             o.di = dv;
         } else {  // rare: a slice off the level's stencil goes through its record / slot headers
+            if constexpr (op_needs_xi(OP)) o.xi = a.x[row];
             bool done = false;
             if (sd_rec) {
                 const SdRecord r = load_sd_record(sd_rec + (size_t)sl * kSdRecInts);
@@ -1027,7 +1094,13 @@ int launch_csr_op(const DevCsr &A, const CsrArgs &a, bool finest, hipStream_t st
             bytes = (size_t)A.sell_entries * 12 + (size_t)A.nrow * 28;
         else
             bytes = (size_t)A.nnz * 12 + (size_t)A.nrow * 36;
-        if (bytes > (240u << 20)) {
+        if (c.kind == 3 && A.has_sdia() && c.table && A.sd_tmask) {
+            // table path: no matrix stream to keep out of the caches; a contiguous eighth per XCD
+            // reads x 1.2x instead of 3.3x and wins inside the solve at every size (216^3: 395 vs
+            // 380 it/s, finest-level sweep 58 vs 65 us; profiles/r01_table_placement_in_solve.txt)
+            nt = false;
+            remap = 1;
+        } else if (bytes > (240u << 20)) {
             nt = true;
             remap = 16;
         } else {

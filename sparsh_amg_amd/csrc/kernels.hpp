@@ -10,6 +10,7 @@ namespace sparsh {
 // level-wide stencil of the sliced-diagonal layout (see DevCsr::sd_tab)
 struct SdTable {
     int nd = 0;
+    int near = 0;  // 73 / 52 / 31: nd = 7 / 5 / 3 with offsets -1, 0, +1 in the three middle slots; else 0
     int off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double cval[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
