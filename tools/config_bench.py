@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Throughput of the other BASELINE.json configurations on one MI355X (they are parity-test cases in
+tests/test_gpu_configs.py; this prints their rates for DESIGN.md / profiles/):
+  C2D  5-pt 2D Poisson 1000^2 (1 M rows): AMG V(7,7) cycles/s and AMG-PCG iterations/s
+  C3D  7-pt 3D Poisson 216^3 (10 M rows): AMG V(7,7) cycles/s (bench.py reports the PCG rate)
+  CU   unstructured P1-FEM M + dt K stand-in, 525 825 rows: AMG-PBiCGStab iterations/s
+All rates are solve-phase only (hierarchy resident, vectors in HBM), full solves to 1e-8.
+Usage: python tools/config_bench.py > profiles/r01_configs.json"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sparsh_amg_amd as sa
+from sparsh_amg_amd import problems
+
+
+def run(name, rp, ci, v, methods):
+    n = len(rp) - 1
+    out = {"rows": n, "nnz": int(rp[-1])}
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, print_solve=0))
+    out["levels"] = [A.level_info(l)["nrow"] for l in range(A.nlevels)]
+    out["level_kernels"] = [A.level_kernel(l) for l in range(A.nlevels - 1)]
+    out["setup_seconds_host"] = round(A.setup_seconds, 3)
+    b = np.ones(n)
+    bd, xd = A.dev_alloc(8 * n), A.dev_alloc(8 * n)
+    A.h2d(bd, b)
+    for m in methods:
+        best = None
+        err = None
+        for rep in range(3):
+            A.h2d(xd, np.zeros(n))
+            try:
+                h, it, sec, rc = A.solve_dev(m, bd, xd)
+            except sa.SparshError as e:  # e.g. BiCGStab breakdown (0/0), which the CPU oracle reproduces
+                err = str(e)
+                break
+            if best is None or sec < best[1]:
+                best = (it, sec, float(h[-1]), rc)
+        if err is not None:
+            out[m] = {"error": err}
+            print(f"[{name}] {m}: {err}", file=sys.stderr, flush=True)
+            continue
+        it, sec, res, rc = best
+        unit = "V-cycles/s" if m == "amg" else "iterations/s"
+        out[m] = {"count": it, "seconds": round(sec, 5), "rate": round(it / sec, 1), "unit": unit, "final_residual": res, "rc": rc}
+        print(f"[{name}] {m}: {it} in {sec:.4f}s = {it / sec:.1f} {unit}, residual {res:.3e}", file=sys.stderr, flush=True)
+    A.close()
+    return out
+
+
+def main():
+    res = {}
+    res["C2D_poisson2d_1000"] = run("C2D", *problems.poisson2d(1000), ["amg", "pcg"])
+    res["C3D_poisson3d_216"] = run("C3D", *problems.poisson3d(216), ["amg", "pcg"])
+    res["CU_fem_unstructured_525825"] = run("CU", *problems.fem_unstructured(), ["pbicg", "pcg"])
+    res["CU_fem_unstructured_60000"] = run("CU60k", *problems.fem_unstructured(60000, seed=7), ["pbicg", "pcg"])
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
