@@ -786,6 +786,7 @@ __device__ __forceinline__ double sdia_tab_apply_near(const SdTable &tab, const 
 
 template <int OP, bool NT, int TAG>
 __global__ __launch_bounds__(kBlock) void sdia_tab_kernel(int nrow, int xlen, int nslice, int ngroups, int remap, SdTable tab,
+                                                           const int *__restrict__ slist,  // optional list of slices (interior / boundary launches)
                                                            const unsigned long long *__restrict__ sd_tmask, const int *__restrict__ sd_tconf,
                                                            const int *__restrict__ sd_ptr, const int *__restrict__ sd_off,
                                                            const unsigned long long *__restrict__ sd_mask, const int *__restrict__ sd_vidx,
@@ -798,8 +799,8 @@ __global__ __launch_bounds__(kBlock) void sdia_tab_kernel(int nrow, int xlen, in
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int idx = __builtin_amdgcn_readfirstlane(gid * (kBlock / 64) + w);
     double acc = 0.0;
-    if (idx < nslice) {
-        const int sl = idx;
+    if (idx < nslice) {  // nslice = number of work items (list length when a list is given)
+        const int sl = slist ? slist[idx] : idx;  // wave-uniform address: scalar load
         int row = sl * 64 + lane;
         const bool has_row = row < nrow;
         if (!has_row) row = nrow - 1;
@@ -1020,13 +1021,15 @@ template <int OP, int TAG>
 int launch_csr_tagged(const DevCsr &A, const CsrArgs &a, bool nt, int remap, hipStream_t st)
 {
     const KernelConfig &c = g_cfg;
-    if (c.kind == 3 && A.has_sdia() && c.table && A.sd_tmask && !a.slice_list) {
-        const int ngroups = (A.nslice + 3) / 4;
+    if (c.kind == 3 && A.has_sdia() && c.table && A.sd_tmask) {
+        const int nwork = a.slice_list ? a.nlist : A.nslice;
+        const int ngroups = (nwork + 3) / 4;
+        if (ngroups <= 0) return 0;
         const int grid = remap_grid(ngroups, remap);
         if (nt)
-            hipLaunchKernelGGL((sdia_tab_kernel<OP, true, TAG>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.ncol, A.nslice, ngroups, remap, A.sd_tab, A.sd_tmask, A.sd_tconf, A.sd_ptr, A.sd_off, A.sd_mask, A.sd_vidx, A.sd_cval, A.sd_val, A.sd_rec, a);
+            hipLaunchKernelGGL((sdia_tab_kernel<OP, true, TAG>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.ncol, nwork, ngroups, remap, A.sd_tab, a.slice_list, A.sd_tmask, A.sd_tconf, A.sd_ptr, A.sd_off, A.sd_mask, A.sd_vidx, A.sd_cval, A.sd_val, A.sd_rec, a);
         else
-            hipLaunchKernelGGL((sdia_tab_kernel<OP, false, TAG>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.ncol, A.nslice, ngroups, remap, A.sd_tab, A.sd_tmask, A.sd_tconf, A.sd_ptr, A.sd_off, A.sd_mask, A.sd_vidx, A.sd_cval, A.sd_val, A.sd_rec, a);
+            hipLaunchKernelGGL((sdia_tab_kernel<OP, false, TAG>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.ncol, nwork, ngroups, remap, A.sd_tab, a.slice_list, A.sd_tmask, A.sd_tconf, A.sd_ptr, A.sd_off, A.sd_mask, A.sd_vidx, A.sd_cval, A.sd_val, A.sd_rec, a);
         return ngroups;
     }
     if (c.kind == 3 && A.has_sdia()) {
