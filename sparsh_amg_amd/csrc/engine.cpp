@@ -766,7 +766,10 @@ void Engine::op_restrict(int l, const double *r, double *bc)
     a.x = r;
     const bool gather = dist_ && !L.replicated && lev_[l + 1].replicated;
     a.y = gather ? bc + gather_part_.lo(comm_->rank) : bc;  // my share of the replicated level's rhs
-    launch_csr(L.R, OP_SPMV, a, false, st_);
+    if (L.P_is_aggregation)
+        launch_restrict_agg(L.R.nrow, L.R.rowptr, L.R.col, r, a.y, st_);
+    else
+        launch_csr(L.R, OP_SPMV, a, false, st_);
     if (gather && !comm_->allgather(bc, gather_part_, st_)) error = "allgather failed: " + comm_->error;
 }
 

@@ -1140,6 +1140,20 @@ __global__ __launch_bounds__(kBlock) void prolong_agg_kernel(int n, const int *_
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) xf[i] = 1.0 * xc[agg[i]] + xf[i];
 }
 
+// b_c[J] = sum of r over the members of aggregate J, in stored (ascending fine row) order: the
+// restriction R = P^T of an aggregation P, whose values are all 1.0 -- the 8-byte value stream of the
+// CSR kernel is skipped, 1.0 * r is r exactly
+__global__ __launch_bounds__(kBlock) void restrict_agg_kernel(int nc, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                               const double *__restrict__ r, double *__restrict__ bc)
+{
+    for (int J = blockIdx.x * kBlock + threadIdx.x; J < nc; J += gridDim.x * kBlock) {
+        const int j0 = rowptr[J], j1 = rowptr[J + 1];
+        double sum = 0.0;
+        for (int j = j0; j < j1; ++j) sum = sum + r[col[j]];
+        bc[J] = sum;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void pack_kernel(int n, const int *__restrict__ idx, const double *__restrict__ vec,
                                                        double *__restrict__ out)
 {
@@ -1302,9 +1316,16 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(int code, int mode,
     double s0 = 0.0, s1 = 0.0;
     if (mode != 2) {
         double a0 = 0.0, a1 = 0.0;
-        for (int i = threadIdx.x; i < nblk; i += kFinBlock) {
-            a0 += p0[i];
-            if (p1) a1 += p1[i];
+        // same order of additions as a plain loop; the unroll only lets 8 loads be in flight per thread
+        if (p1) {
+#pragma unroll 8
+            for (int i = threadIdx.x; i < nblk; i += kFinBlock) {
+                a0 += p0[i];
+                a1 += p1[i];
+            }
+        } else {
+#pragma unroll 8
+            for (int i = threadIdx.x; i < nblk; i += kFinBlock) a0 += p0[i];
         }
         a0 = wave_sum(a0);
         a1 = wave_sum(a1);
@@ -1465,6 +1486,12 @@ void launch_prolong_agg(int n, const int *agg, const double *xc, double *xf, hip
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(prolong_agg_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, st, n, agg, xc, xf);
+}
+
+void launch_restrict_agg(int nc, const int *rowptr, const int *col, const double *r, double *bc, hipStream_t st)
+{
+    if (nc <= 0) return;
+    hipLaunchKernelGGL(restrict_agg_kernel, dim3(ew_grid(nc)), dim3(kBlock), 0, st, nc, rowptr, col, r, bc);
 }
 
 void launch_gemv(int n, const double *M, const double *b, double *x, hipStream_t st)

@@ -129,6 +129,8 @@ int launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool finest, hipStre
 void launch_jacobi_zero(int n, const double *b, const double *d, double omega, double *x, hipStream_t st);
 // xf_i = xc[agg_i] + xf_i : prolongation for an aggregation P (one unit entry per row)
 void launch_prolong_agg(int n, const int *agg, const double *xc, double *xf, hipStream_t st);
+// bc[J] = sum of r over aggregate J (R = P^T of an aggregation P: all values 1.0, not read)
+void launch_restrict_agg(int nc, const int *rowptr, const int *col, const double *r, double *bc, hipStream_t st);
 // x = A^{-1} b with the explicit row-major inverse (coarsest level)
 void launch_gemv(int n, const double *M, const double *b, double *x, hipStream_t st);
 
