@@ -374,3 +374,38 @@ def test_constant_slot_folding_bitwise():
                 sa.set_kernel_config()
         A.close()
         B.close()
+
+
+def _banded(n, offs, vals):
+    import scipy.sparse as sp
+
+    A = sp.diags([np.full(n - abs(o), float(c)) for o, c in zip(offs, vals)], offs, shape=(n, n), format="csr")
+    A.sort_indices()
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+
+
+@pytest.mark.parametrize("name,offs,vals", [
+    ("lap1d", [-1, 0, 1], [-1, 2.5, -1]),                          # near-gather variant <3,1>
+    ("skew5", [-40, -3, 0, 3, 40], [-1, -0.5, 4, -0.5, -1]),         # table without the -1/0/+1 triple
+    ("band7", [-3, -2, -1, 0, 1, 2, 3], [-0.25, -0.5, -1, 5, -1, -0.5, -0.25]),  # <7,3> with near far-bands
+])
+def test_table_kernel_variants_bitwise(name, offs, vals):
+    """Every code path of the stencil-table kernel on synthetic constant-band operators whose first
+    and last slices are ragged (n is not a multiple of 64): SpMV, residual, fused Jacobi sweeps and
+    the fused residual norm against the oracle, bit for bit."""
+    n = 64 * 37 + 29
+    rp, ci, v = _banded(n, offs, vals)
+    O = oracle.Csr(rp, ci, v)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(n)
+    b = rng.standard_normal(n)
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET, max_levels=2, coarse_limit=1 << 20, limit_upper=1 << 20))
+    try:
+        assert A.level_kernel(0) == "sdia_tab_kernel", A.level_kernel(0)
+        assert np.array_equal(A.op_spmv(0, x), oracle.spmv(O, x))
+        assert np.array_equal(A.op_residual(0, b, x), oracle.store_residual(O, b, x))
+        rn = A.op_resnorm(0, b, x)
+        assert abs(rn - oracle.residual(O, b, x)) <= 1e-12 * rn
+        assert np.array_equal(A.op_jacobi(0, b, x, 3), oracle.jacobi(O, b, x, 2))
+    finally:
+        A.close()
