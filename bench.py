@@ -345,11 +345,32 @@ def main():
         _, ho, sec = H.pcg(b, max_it=args.cpu_iters)
         log(f"cpu_baseline: done in {sec:.1f}s")
         cpu_its = len(ho) / sec
+        # the reference's own thread setting (`th` = 2, include/AMG.hpp:15) on a short sample
+        two = None
+        try:
+            H2 = oracle.Hierarchy(OA, oracle.params(threads=2, max_levels=len(levels), tol=0.0))
+            _, h2, sec2 = H2.pcg(b, max_it=3)
+            two = {"value": round(len(h2) / sec2, 4), "unit": "iterations/s", "cores": 2,
+                   "sample": f"{len(h2)} iterations, {sec2:.1f} s (the reference's compile-time default th = 2)"}
+            del H2
+        except Exception as e:  # noqa: BLE001
+            two = {"error": repr(e)}
+        cpu_model = "unknown"
+        try:
+            for ln in open("/proc/cpuinfo"):
+                if ln.startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
+        log(f"cpu_baseline: {cpu_its:.2f} it/s with {ncores} threads on {cpu_model}")
         cpu = {
             "value": round(cpu_its, 4), "unit": "iterations/s", "cores": ncores, "kind": "port",
             "sample": f"{len(ho)} AMG-PCG iterations of oracle/amg_oracle.c (OpenMP, {ncores} threads) on the same "
                       f"{n}-row matrix and same level count; solve loop only ({sec:.1f} s; oracle setup {t_setup:.1f} s excluded)",
             "gbs": round(it_bytes * cpu_its / 1e9, 1),
+            "cpu_model": cpu_model, "host_cpus_visible": os.cpu_count(),
+            "reference_default_2_threads": two,
             "first_residuals_match_gpu": bool(np.allclose(ho[: min(len(ho), len(hist))], hist[: min(len(ho), len(hist))], rtol=1e-6)),
         }
 

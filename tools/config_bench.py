@@ -18,10 +18,10 @@ import sparsh_amg_amd as sa
 from sparsh_amg_amd import problems
 
 
-def run(name, rp, ci, v, methods):
+def run(name, rp, ci, v, methods, **params):
     n = len(rp) - 1
     out = {"rows": n, "nnz": int(rp[-1])}
-    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, print_solve=0))
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, print_solve=0, **params))
     out["levels"] = [A.level_info(l)["nrow"] for l in range(A.nlevels)]
     out["level_kernels"] = [A.level_kernel(l) for l in range(A.nlevels - 1)]
     out["setup_seconds_host"] = round(A.setup_seconds, 3)
@@ -56,6 +56,8 @@ def main():
     res = {}
     res["C2D_poisson2d_1000"] = run("C2D", *problems.poisson2d(1000), ["amg", "pcg"])
     res["C3D_poisson3d_216"] = run("C3D", *problems.poisson3d(216), ["amg", "pcg"])
+    # nu = 6 sweeps: what the reference's GPU path effectively runs (smooth_iter without the +1 of the CPU path)
+    res["C3D_poisson3d_216_nu6"] = run("C3D nu=6", *problems.poisson3d(216), ["amg", "pcg"], sweeps=6)
     res["CU_fem_unstructured_525825"] = run("CU", *problems.fem_unstructured(), ["pbicg", "pcg"])
     res["CU_fem_unstructured_60000"] = run("CU60k", *problems.fem_unstructured(60000, seed=7), ["pbicg", "pcg"])
     print(json.dumps(res, indent=1))

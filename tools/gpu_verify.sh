@@ -10,6 +10,7 @@ python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1 || { tail -3
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1 || exit 2
 python bench.py > gpurun_out/bench_latest.json 2> gpurun_out/bench_latest.err || exit 3
 python tools/kernel_bench.py --levels 13 > gpurun_out/kb_final.txt 2>&1 || exit 4
+python tools/config_bench.py > gpurun_out/configs.json 2> gpurun_out/configs.err || exit 9
 cd /tmp
 rm -rf $R/gpurun_out/prof_stats $R/gpurun_out/pmc_run
 SPARSH_BENCH_NO_CPU=1 SPARSH_BENCH_NO_GENERAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python3 $R/bench.py > $R/gpurun_out/prof_stats_bench.json 2> $R/gpurun_out/prof_stats.err || exit 5
