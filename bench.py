@@ -238,10 +238,14 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "kernel": f"{fmt_name}<OP_JACOBI=2, NT=true, TAG=1> (fused Jacobi sweep, finest level)", "launches": pr["launches"],
             "avg_us": round(avg * 1e6, 2), "bytes_per_launch": jac_bytes,
-            "note": "achieved/frac use the CSR byte model of SURVEY §8d (12*nnz + 36*n); the kernel's own layout streams "
-                    "layout_bytes_per_launch, i.e. layout_GBps of real traffic",
+            "note": "achieved/frac use the CSR byte model of SURVEY §8d (12*nnz + 36*n); the kernel's own layout (no column indices, "
+                    "constant diagonals folded into scalars) has to move layout_bytes_per_launch = layout_GBps; traffic = PMC bytes per "
+                    "launch (profiles/pmc_latest.json) = traffic_GBps.  With the values folded away the sweep is bound by the bytes "
+                    "L2 delivers to the CUs, not by HBM (DESIGN.md section 4)",
             "layout_bytes_per_launch": fmt_bytes, "layout_GBps": round(fmt_bytes / avg / 1e9, 1),
             "layout_frac": round(fmt_bytes / avg / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic_GBps": round(traffic / avg / 1e9, 1) if traffic else None,
+            "traffic_frac": round(traffic / avg / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
             "layout": {"slots": slots, "value_blocks": vblocks, "constant_slots": slots - vblocks, "descriptor_bytes": meta_bytes} if fmt == 3 else None,
         }
 
