@@ -715,15 +715,15 @@ int Engine::apply_A(DevLevel &L, CsrOp op, CsrArgs a)
 
 // Reduce per-workgroup partials and update the device scalars; across ranks the local sums are
 // all-reduced in between (one 16-byte ncclAllReduce).
-void Engine::finalize(Fin code, const double *p0, const double *p1, int nblk, int slot, double *hist, int it)
+void Engine::finalize(Fin code, const double *p0, const double *p1, int nblk, int slot, double *hist, int it, int nblk1)
 {
     if (!dist_) {
-        launch_finalize(code, p0, p1, nblk, scal_, slot, hist, it, st_, 0, iter_ctr_, hist_cap_dev_);
+        launch_finalize(code, p0, p1, nblk, scal_, slot, hist, it, st_, 0, iter_ctr_, hist_cap_dev_, nblk1);
         return;
     }
-    launch_finalize(code, p0, p1, nblk, scal_, slot, hist, it, st_, 1, iter_ctr_, hist_cap_dev_);
+    launch_finalize(code, p0, p1, nblk, scal_, slot, hist, it, st_, 1, iter_ctr_, hist_cap_dev_, nblk1);
     if (!comm_->allreduce_sum(scal_ + S_SUM0, 2, st_)) error = "allreduce failed: " + comm_->error;
-    launch_finalize(code, p0, p1, nblk, scal_, slot, hist, it, st_, 2, iter_ctr_, hist_cap_dev_);
+    launch_finalize(code, p0, p1, nblk, scal_, slot, hist, it, st_, 2, iter_ctr_, hist_cap_dev_, nblk1);
 }
 
 // ---------------------------------------------------------------------------- operators
@@ -961,16 +961,18 @@ void Engine::pcg_body(bool precond, int slot)
     a.partial = part0_;
     const int np = apply_A(lev_[0], OP_SPMV_DOT, a);  // Ap = A p ; p.Ap
     finalize(precond ? FIN_PCG_ALPHA : FIN_CG_ALPHA, part0_, nullptr, np, 0, nullptr, 0);
-    launch_cg_update(n, scal_, p, Ap, x, r, part0_, &nb, st_);  // x += alpha p ; r -= alpha Ap ; r.r
+    // x += alpha p ; r -= alpha Ap ; r.r -- with a preconditioner the r.r partials wait in part1_ and
+    // are reduced together with z.r after the V-cycle: one finalize launch (one all-reduce) less
+    launch_cg_update(n, scal_, p, Ap, x, r, precond ? part1_ : part0_, &nb, st_);
     if (precond && f32_ready_) {
-        finalize(FIN_SQRT, part0_, nullptr, nb, S_RES, hist_dev_, slot);
+        const int nb_rr = nb;
         vcycle_f32(r, work_[4], part0_, &nb);  // float hierarchy, fp64 in/out, fused z0.r0
-        finalize(FIN_PCG_BETA, part0_, nullptr, nb, 0, nullptr, 0);
+        finalize(FIN_PCG_BETA_RES, part0_, part1_, nb, 0, hist_dev_, slot, nb_rr);
         launch_p_update(n, scal_, work_[4], p, st_);
     } else if (precond) {
-        finalize(FIN_SQRT, part0_, nullptr, nb, S_RES, hist_dev_, slot);
+        const int nb_rr = nb;
         vcycle(r, true, part0_, &nb);  // z0 = 0 ; z0 = V(r0) ; fused z0.r0
-        finalize(FIN_PCG_BETA, part0_, nullptr, nb, 0, nullptr, 0);
+        finalize(FIN_PCG_BETA_RES, part0_, part1_, nb, 0, hist_dev_, slot, nb_rr);
         launch_p_update(n, scal_, lev_[0].x, p, st_);  // p = z0 + beta p
     } else {
         finalize(FIN_CG_BETA, part0_, nullptr, nb, 0, hist_dev_, slot);

@@ -132,7 +132,7 @@ private:
     // exchange runs on a second stream while the slices that touch no halo column are processed.
     // Returns the number of reduction partials written.
     int apply_A(DevLevel &L, CsrOp op, CsrArgs a);
-    void finalize(Fin code, const double *p0, const double *p1, int nblk, int slot, double *hist, int it);
+    void finalize(Fin code, const double *p0, const double *p1, int nblk, int slot, double *hist, int it, int nblk1 = -1);
     bool upload_plan(const HaloPlan &h, DevPlan &d);
     double read_scalar(int slot);
     double read_hist(int it);

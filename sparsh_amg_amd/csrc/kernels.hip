@@ -1308,7 +1308,7 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(int n, const double *__res
 constexpr int kFinBlock = 1024;
 
 __global__ __launch_bounds__(kFinBlock) void finalize_kernel(int code, int mode, const double *__restrict__ p0,
-                                                              const double *__restrict__ p1, int nblk, double *__restrict__ scal,
+                                                              const double *__restrict__ p1, int nblk, int nblk1, double *__restrict__ scal,
                                                               int slot_a, double *__restrict__ hist, int it, int *__restrict__ iter_ctr,
                                                               int hist_cap)
 {
@@ -1317,15 +1317,11 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(int code, int mode,
     if (mode != 2) {
         double a0 = 0.0, a1 = 0.0;
         // same order of additions as a plain loop; the unroll only lets 8 loads be in flight per thread
-        if (p1) {
 #pragma unroll 8
-            for (int i = threadIdx.x; i < nblk; i += kFinBlock) {
-                a0 += p0[i];
-                a1 += p1[i];
-            }
-        } else {
+        for (int i = threadIdx.x; i < nblk; i += kFinBlock) a0 += p0[i];
+        if (p1) {  // the second array may come from a different kernel (its own partial count)
 #pragma unroll 8
-            for (int i = threadIdx.x; i < nblk; i += kFinBlock) a0 += p0[i];
+            for (int i = threadIdx.x; i < nblk1; i += kFinBlock) a1 += p1[i];
         }
         a0 = wave_sum(a0);
         a1 = wave_sum(a1);
@@ -1372,6 +1368,14 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(int code, int mode,
         scal[S_ZR] = s0;
         scal[S_BETA] = s0 / scal[S_RZ];
         scal[S_RZ] = s0;
+    } break;
+    case FIN_PCG_BETA_RES: {  // FIN_PCG_BETA and the residual norm of the same iteration in one launch / one all-reduce
+        scal[S_ZR] = s0;
+        scal[S_BETA] = s0 / scal[S_RZ];
+        scal[S_RZ] = s0;
+        const double v = sqrt(s1);
+        scal[S_RES] = v;
+        if (hist) hist[hslot] = v;
     } break;
     case FIN_CG_ALPHA: {
         scal[S_PAP] = s0;
@@ -1541,10 +1545,10 @@ void launch_dot2(int n, const double *a, const double *b, const double *c, const
 }
 
 void launch_finalize(Fin code, const double *partial0, const double *partial1, int nblk, double *scal, int slot_a, double *hist,
-                     int it, hipStream_t st, int mode, int *iter_ctr, int hist_cap)
+                     int it, hipStream_t st, int mode, int *iter_ctr, int hist_cap, int nblk1)
 {
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(mode == 2 ? 64 : kFinBlock), 0, st, (int)code, mode, partial0, partial1, nblk, scal,
-                       slot_a, hist, it, iter_ctr, hist_cap);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(mode == 2 ? 64 : kFinBlock), 0, st, (int)code, mode, partial0, partial1, nblk,
+                       nblk1 >= 0 ? nblk1 : nblk, scal, slot_a, hist, it, iter_ctr, hist_cap);
 }
 
 void launch_pack(int n, const int *idx, const double *vec, double *sendbuf, hipStream_t st)

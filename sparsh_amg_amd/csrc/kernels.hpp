@@ -182,13 +182,15 @@ enum Fin : int {
     FIN_CG_ALPHA = 5,  // pAp=sum0 ; alpha = rr/pAp ; nalpha = -alpha
     FIN_BICG_ALPHA = 6,// alpha1 = sum0 (r.r0) ; apr0 = sum1 (Ap.r0) ; alpha = alpha1/apr0
     FIN_BICG_OMEGA = 7,// ass = sum0 (As.s) ; asas = sum1 (As.As) ; omega1 = ass/asas
-    FIN_BICG_BETA = 8  // rr0 = sum0 (r.r0) ; rr = sum1 (r.r) ; beta = rr0/alpha1*(alpha/omega1) ; res = sqrt(rr) ; hist
+    FIN_BICG_BETA = 8, // rr0 = sum0 (r.r0) ; rr = sum1 (r.r) ; beta = rr0/alpha1*(alpha/omega1) ; res = sqrt(rr) ; hist
+    FIN_PCG_BETA_RES = 9  // FIN_PCG_BETA on sum0 (z.r) and res = sqrt(sum1) (r.r) ; hist
 };
 // it >= 0: residual-history slot; it < 0: take the slot from the device counter *iter_ctr (graph replays).
 // mode 0: reduce the partials and apply `code` (single GPU); mode 1: reduce only, local sums to
 // scal[S_SUM0], scal[S_SUM1] (then all-reduced across ranks); mode 2: apply `code` to those sums
 void launch_finalize(Fin code, const double *partial0, const double *partial1, int nblk, double *scal, int slot_a,
-                     double *hist, int it, hipStream_t st, int mode = 0, int *iter_ctr = nullptr, int hist_cap = 1 << 30);
+                     double *hist, int it, hipStream_t st, int mode = 0, int *iter_ctr = nullptr, int hist_cap = 1 << 30,
+                     int nblk1 = -1);  // nblk1: length of partial1 when it differs from nblk
 // sendbuf[k] = vec[idx[k]] : pack the entries the peers need (halo exchange)
 void launch_pack(int n, const int *idx, const double *vec, double *sendbuf, hipStream_t st);
 
