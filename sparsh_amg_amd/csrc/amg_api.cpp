@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cctype>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -156,6 +158,126 @@ void readcoo(char *matrixfile, char *rhsfile, sp_matrix_mg *&A, double *&b)
         rin >> b[i];
         A->rowptr[i + 1] += A->rowptr[i];
     }
+}
+
+bool read_matrix_market(const char *file, sp_matrix_mg *&A)
+{
+    A = nullptr;
+    std::ifstream in(file);
+    if (!in) {
+        std::cout << "Cannot open " << file << std::endl;
+        return false;
+    }
+    std::string line;
+    if (!std::getline(in, line) || line.compare(0, 14, "%%MatrixMarket") != 0) {
+        std::cout << file << ": not a MatrixMarket file" << std::endl;
+        return false;
+    }
+    std::string low(line);
+    for (char &c : low) c = (char)std::tolower((unsigned char)c);
+    if (low.find("coordinate") == std::string::npos || low.find("complex") != std::string::npos) {
+        std::cout << file << ": only real / integer / pattern coordinate matrices are supported" << std::endl;
+        return false;
+    }
+    const bool pattern = low.find("pattern") != std::string::npos;
+    const bool symmetric = low.find("symmetric") != std::string::npos && low.find("skew") == std::string::npos;
+    const bool skew = low.find("skew-symmetric") != std::string::npos;
+    while (std::getline(in, line))
+        if (!line.empty() && line[0] != '%') break;
+    long nrow = 0, ncol = 0, nent = 0;
+    {
+        std::istringstream hs(line);
+        if (!(hs >> nrow >> ncol >> nent) || nrow <= 0 || ncol <= 0 || nent < 0) {
+            std::cout << file << ": bad size line" << std::endl;
+            return false;
+        }
+    }
+    struct Ent {
+        int r, c;
+        double v;
+    };
+    std::vector<Ent> e;
+    e.reserve((size_t)nent * ((symmetric || skew) ? 2 : 1));
+    for (long k = 0; k < nent; ++k) {
+        long r = 0, c = 0;
+        double v = 1.0;
+        if (!(in >> r >> c) || (!pattern && !(in >> v)) || r < 1 || c < 1 || r > nrow || c > ncol) {
+            std::cout << file << ": bad entry " << k + 1 << std::endl;
+            return false;
+        }
+        e.push_back({(int)(r - 1), (int)(c - 1), v});
+        if ((symmetric || skew) && r != c) e.push_back({(int)(c - 1), (int)(r - 1), skew ? -v : v});
+    }
+    std::stable_sort(e.begin(), e.end(), [](const Ent &a, const Ent &b) { return a.r != b.r ? a.r < b.r : a.c < b.c; });
+    size_t m = 0;  // sum duplicates in file order
+    for (size_t k = 0; k < e.size(); ++k) {
+        if (m > 0 && e[m - 1].r == e[k].r && e[m - 1].c == e[k].c)
+            e[m - 1].v += e[k].v;
+        else
+            e[m++] = e[k];
+    }
+    if (m >= (size_t)1 << 31) {
+        std::cout << file << ": more than 2^31 - 1 entries" << std::endl;
+        return false;
+    }
+    A = new sp_matrix_mg((int)nrow, (int)ncol, (int)m);
+    for (size_t k = 0; k < m; ++k) {
+        A->rowptr[e[k].r + 1]++;
+        A->colindex[k] = e[k].c;
+        A->val[k] = e[k].v;
+    }
+    for (long i = 0; i < nrow; ++i) A->rowptr[i + 1] += A->rowptr[i];
+    return true;
+}
+
+namespace {
+const char kBinMagic[8] = {'S', 'P', 'A', 'R', 'S', 'H', 'B', '1'};
+}
+
+bool write_csr_binary(const char *file, const sp_matrix_mg &A)
+{
+    std::ofstream out(file, std::ios::binary);
+    if (!out) return false;
+    const int nnz = A.rowptr[A.nrow];
+    const int hdr[3] = {A.nrow, A.ncol, nnz};
+    out.write(kBinMagic, 8);
+    out.write(reinterpret_cast<const char *>(hdr), sizeof(hdr));
+    out.write(reinterpret_cast<const char *>(A.rowptr), sizeof(int) * ((size_t)A.nrow + 1));
+    out.write(reinterpret_cast<const char *>(A.colindex), sizeof(int) * (size_t)nnz);
+    out.write(reinterpret_cast<const char *>(A.val), sizeof(double) * (size_t)nnz);
+    return (bool)out;
+}
+
+bool read_csr_binary(const char *file, sp_matrix_mg *&A)
+{
+    A = nullptr;
+    std::ifstream in(file, std::ios::binary);
+    if (!in) {
+        std::cout << "Cannot open " << file << std::endl;
+        return false;
+    }
+    char magic[8];
+    int hdr[3] = {0, 0, 0};
+    in.read(magic, 8);
+    in.read(reinterpret_cast<char *>(hdr), sizeof(hdr));
+    if (!in || std::memcmp(magic, kBinMagic, 8) != 0 || hdr[0] <= 0 || hdr[1] <= 0 || hdr[2] < 0) {
+        std::cout << file << ": not a sparsh binary CSR file" << std::endl;
+        return false;
+    }
+    sp_matrix_mg *M = new sp_matrix_mg(hdr[0], hdr[1], hdr[2]);
+    in.read(reinterpret_cast<char *>(M->rowptr), sizeof(int) * ((size_t)hdr[0] + 1));
+    in.read(reinterpret_cast<char *>(M->colindex), sizeof(int) * (size_t)hdr[2]);
+    in.read(reinterpret_cast<char *>(M->val), sizeof(double) * (size_t)hdr[2]);
+    bool ok = (bool)in && M->rowptr[0] == 0 && M->rowptr[hdr[0]] == hdr[2];
+    for (int i = 0; ok && i < hdr[0]; ++i) ok = M->rowptr[i] <= M->rowptr[i + 1];
+    for (int k = 0; ok && k < hdr[2]; ++k) ok = M->colindex[k] >= 0 && M->colindex[k] < hdr[1];
+    if (!ok) {
+        std::cout << file << ": truncated or inconsistent binary CSR file" << std::endl;
+        delete M;
+        return false;
+    }
+    A = M;
+    return true;
 }
 
 void read_coo_new_format(char *matrixfile, sp_matrix_mg *&A, double *&b)

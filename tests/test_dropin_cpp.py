@@ -3,6 +3,8 @@ library (drop-in boundary).  Compiled in place from /root/reference
 only; nothing is copied).  Running it needs a GPU, so this CPU test stops at the link step and
 checks that every C++ entry point of include/AMG.hpp is exported."""
 import os
+
+import numpy as np
 import re
 import subprocess
 
@@ -140,3 +142,77 @@ def test_readcoo_roundtrip(tmp_path):
     out = subprocess.check_output([str(exe), mf, rf], text=True).split()
     assert int(out[0]) == len(rp) - 1 and int(out[2]) == rp[-1]
     assert float(out[3]) == 4.0 and float(out[4]) == b[5] and int(out[5]) == ci[7]
+
+
+def test_matrix_market_reader_and_binary_cache(tmp_path):
+    """read_matrix_market (1-based, comments, symmetric expansion, unordered entries, duplicates summed,
+    pattern) and the binary CSR cache round trip -- host code, no GPU."""
+    import scipy.io
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(4)
+    n = 37
+    B = sp.random(n, n, density=0.15, random_state=5, format="coo")
+    S = (B + B.T + sp.identity(n) * 3.0).tocoo()
+    gen = tmp_path / "general.mtx"
+    sym = tmp_path / "symmetric.mtx"
+    scipy.io.mmwrite(str(gen), B.tocoo(), comment="general, unordered")
+    scipy.io.mmwrite(str(sym), sp.tril(S).tocoo(), symmetry="symmetric")
+    dup = tmp_path / "dups.mtx"
+    dup.write_text("%%MatrixMarket matrix coordinate real general\n% duplicates are summed\n3 3 5\n3 1 2.0\n1 1 1.0\n3 1 0.5\n2 2 4.0\n1 3 -1.0\n")
+    pat = tmp_path / "pattern.mtx"
+    pat.write_text("%%MatrixMarket matrix coordinate pattern symmetric\n3 3 3\n1 1\n3 1\n2 2\n")
+    src = tmp_path / "mm.cpp"
+    src.write_text(r'''
+#include "AMG.hpp"
+#include <cstdio>
+static void dump(const char *tag, sp_matrix_mg *A)
+{
+    std::printf("%s %d %d %d", tag, A->nrow, A->ncol, A->rowptr[A->nrow]);
+    double s = 0; long cs = 0;
+    for (int i = 0; i < A->nrow; i++)
+        for (int j = A->rowptr[i]; j < A->rowptr[i + 1]; j++) { s += A->val[j] * (i + 1) * (A->colindex[j] + 2); cs += A->colindex[j]; if (j > A->rowptr[i] && A->colindex[j] <= A->colindex[j - 1]) cs = -1000000; }
+    std::printf(" %.15g %ld\n", s, cs);
+}
+int main(int argc, char **argv)
+{
+    sp_matrix_mg *A = nullptr, *B = nullptr;
+    for (int k = 1; k <= 4; k++) {
+        if (!read_matrix_market(argv[k], A)) return 10 + k;
+        dump(argv[k], A);
+        if (k == 2) {
+            if (!write_csr_binary(argv[5], *A) || !read_csr_binary(argv[5], B)) return 20;
+            dump("binary", B);
+            delete B;
+        }
+        delete A;
+    }
+    if (read_matrix_market(argv[5], A) || A != nullptr) return 30;  // not a MatrixMarket file
+    if (read_csr_binary(argv[1], A) || A != nullptr) return 31;     // not a binary file
+    return 0;
+}
+''')
+    exe = tmp_path / "mm"
+    cmd = ["g++", "-std=c++17", "-O1", f"-I{os.path.join(ROOT, 'include')}", str(src), "-o", str(exe),
+           f"-L{LIB_DIR}", "-lsparsh_amg", f"-Wl,-rpath,{LIB_DIR}", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib/llvm/lib",
+           "-L/opt/rocm/lib", "-L/opt/rocm/lib/llvm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe), str(gen), str(sym), str(dup), str(pat), str(tmp_path / "cache.bin")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+
+    def expect(M):
+        M = sp.csr_matrix(M)
+        M.sum_duplicates()
+        M.sort_indices()
+        rows = np.repeat(np.arange(M.shape[0]), np.diff(M.indptr))
+        return M.shape[0], M.shape[1], M.nnz, float(np.sum(M.data * (rows + 1) * (M.indices + 2))), int(M.indices.sum())
+
+    lines = [ln.split() for ln in r.stdout.strip().splitlines() if len(ln.split()) == 6]
+    got = {os.path.basename(t[0]): (int(t[1]), int(t[2]), int(t[3]), float(t[4]), int(t[5])) for t in lines}
+    D = sp.coo_matrix(([2.0, 1.0, 0.5, 4.0, -1.0], ([2, 0, 2, 1, 0], [0, 0, 0, 1, 2])), shape=(3, 3))
+    P = sp.coo_matrix(([1.0, 1.0, 1.0, 1.0], ([0, 2, 0, 1], [0, 0, 2, 1])), shape=(3, 3))
+    for name, M in (("general.mtx", B), ("symmetric.mtx", S), ("binary", S), ("dups.mtx", D), ("pattern.mtx", P)):
+        e = expect(M)
+        g = got[name]
+        assert g[:3] == e[:3] and g[4] == e[4] and abs(g[3] - e[3]) <= 1e-12 * max(1.0, abs(e[3])), (name, g, e)
