@@ -4,6 +4,7 @@ tests/test_gpu_configs.py; this prints their rates for DESIGN.md / profiles/):
   C2D  5-pt 2D Poisson 1000^2 (1 M rows): AMG V(7,7) cycles/s and AMG-PCG iterations/s
   C3D  7-pt 3D Poisson 216^3 (10 M rows): AMG V(7,7) cycles/s (bench.py reports the PCG rate)
   CU   unstructured P1-FEM M + dt K stand-in, 525 825 rows: AMG-PBiCGStab iterations/s
+SPARSH_MTX=/path/to/file.mtx adds that MatrixMarket file as a further CU case.
 All rates are solve-phase only (hierarchy resident, vectors in HBM), full solves to 1e-8.
 Usage: python tools/config_bench.py > profiles/r01_configs.json"""
 import json
@@ -58,6 +59,9 @@ def main():
     res["C3D_poisson3d_216"] = run("C3D", *problems.poisson3d(216), ["amg", "pcg"])
     # nu = 6 sweeps: what the reference's GPU path effectively runs (smooth_iter without the +1 of the CPU path)
     res["C3D_poisson3d_216_nu6"] = run("C3D nu=6", *problems.poisson3d(216), ["amg", "pcg"], sweeps=6)
+    mtx = os.environ.get("SPARSH_MTX")  # e.g. SuiteSparse parabolic_fem.mtx when it is on the box
+    if mtx and os.path.exists(mtx):
+        res["CU_" + os.path.basename(mtx)] = run("CU file", *problems.read_matrix_market(mtx), ["pbicg", "pcg"])
     res["CU_fem_unstructured_525825"] = run("CU", *problems.fem_unstructured(), ["pbicg", "pcg"])
     res["CU_fem_unstructured_60000"] = run("CU60k", *problems.fem_unstructured(60000, seed=7), ["pbicg", "pcg"])
     print(json.dumps(res, indent=1))
