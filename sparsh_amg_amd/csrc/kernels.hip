@@ -1,6 +1,18 @@
 // kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, CDNA4): the AMG solve-phase
 // operators.  Wave = 64 lanes, workgroup = 256 threads (one wave per SIMD).  All kernels are
-// HBM-bandwidth bound (SpMV: 2 flop per 12 B); there is no MFMA here on purpose.
+// memory bound (SpMV: 2 flop per 12 B); there is no MFMA here on purpose.
+//
+// SpMV-type operators (y = A x with a fused epilogue OP_*: SpMV, residual, Jacobi sweep, p.Ap,
+// ||Ax-b||^2, ...) exist in these families, all bitwise identical, chosen per operator at launch:
+//   csr_block_kernel / csr_wave_kernel   CSR-stream, any matrix (irregular operators, P, R)
+//   sell_kernel                          sliced ELL (64-row slices), near-uniform row lengths
+//   sdia_kernel                          sliced diagonals: per slice the distinct offsets once, no
+//                                        column indices; paths per slice: general (value blocks),
+//                                        plain (no constant slot), const (> 8 constant slots),
+//                                        record (<= 8 constant slots, one 192-B descriptor)
+//   sdia_tab_kernel                      sliced diagonals with a level-wide stencil passed as kernel
+//                                        arguments, 64-B lane-mask record per slice; near variant:
+//                                        x[r-1], x[r], x[r+1] from one gather (DPP + scalar edge loads)
 //
 // Arithmetic contract (parity with the reference's CPU path, built with -ffp-contract=off):
 //   * a row sum adds the products a_ij*x_j one by one in stored column order, each product
