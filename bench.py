@@ -312,6 +312,24 @@ def main():
                    "note": "constant-slot folding off: the layout a variable-coefficient operator gets (8 B per stored entry)"}
         A2.close()
 
+    # multi-GPU diagnostics for tuning (collective calls, every rank): what one halo exchange, one
+    # scalar all-reduce and the all-gather at the replication boundary cost on this node
+    comm_us = None
+    if mode == "partitioned":
+        try:
+            comm_us = {"halo_exchange_level": {}, "note": "average of 50 back-to-back steps alone on the engine's stream (HIP events, rank 0)"}
+            for l in range(A.nlevels):
+                if A.local_range(l)[2]:
+                    break
+                t_h = A.bench_comm("halo", l, 50)
+                comm_us["halo_exchange_level"][str(l)] = round(t_h * 1e6, 2) if t_h >= 0 else None
+            t_r = A.bench_comm("allreduce", 0, 50)
+            t_g = A.bench_comm("allgather", 0, 20)
+            comm_us["allreduce_16B"] = round(t_r * 1e6, 2) if t_r >= 0 else None
+            comm_us["allgather_at_replication_boundary"] = round(t_g * 1e6, 2) if t_g >= 0 else None
+        except Exception as e:  # noqa: BLE001
+            comm_us = {"error": repr(e)}
+
     # multi-GPU parity: rank 0 repeats the same iterations on ONE GPU (fresh handle, no transport)
     # and compares residual histories; the other ranks wait at the barrier below.
     parity = None
@@ -409,6 +427,7 @@ def main():
                 "solve_restarted_every": RESTART,
                 "full_solve_to_1e-8": full,
                 "general_values_layout": general,
+                "comm_us": comm_us,
                 "setup_seconds_host": round(A.setup_seconds, 2),
                 "generate_seconds": round(t_gen, 2),
             },

@@ -124,6 +124,12 @@ int sparsh_level_format(sparsh_handle h, int level, int *kind, long *stored_entr
  * measurements; default on). */
 int sparsh_level_layout(sparsh_handle h, int level, long *slots, long *value_blocks, long *meta_bytes);
 int sparsh_set_const_slots(int enable);
+/* Multi-GPU diagnostics (collective: every rank calls it with the same arguments): average seconds
+ * of one communication step alone, timed with HIP events on the engine's stream.  what = 0: halo
+ * exchange of level `level`'s operator; 1: the 16-byte all-reduce of the fused scalars; 2: the
+ * all-gather at the partitioned -> replicated boundary.  *avg_seconds = -1 when there is no such
+ * step (single GPU, replicated level). */
+int sparsh_bench_comm(sparsh_handle h, int what, int level, int reps, double *avg_seconds);
 /* name of the kernel the SpMV-type operations of a level launch under the current config
  * ("sdia_tab_kernel", "sdia_kernel", "sell_kernel", "csr_wave_kernel", "csr_block_kernel") */
 const char *sparsh_level_kernel(sparsh_handle h, int level);

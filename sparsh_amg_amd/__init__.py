@@ -84,6 +84,7 @@ def _load():
         "sparsh_level_format": (C.c_int, [H, C.c_int, c_int_p, C.POINTER(C.c_long)]),
         "sparsh_level_layout": (C.c_int, [H, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
         "sparsh_set_const_slots": (C.c_int, [C.c_int]),
+        "sparsh_bench_comm": (C.c_int, [H, C.c_int, C.c_int, C.c_int, c_dbl_p]),
         "sparsh_level_kernel": (C.c_char_p, [H, C.c_int]),
         "sparsh_num_levels": (C.c_int, [H]),
         "sparsh_level_info": (C.c_int, [H, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p]),
@@ -262,6 +263,12 @@ class sp_matrix_mg:
         k, e = C.c_int(), C.c_long()
         _check(lib.sparsh_level_format(self._h, level, C.byref(k), C.byref(e)))
         return k.value, e.value
+
+    def bench_comm(self, what, level=0, reps=50):
+        """Average seconds of one communication step alone (collective); -1 when there is none."""
+        sec = C.c_double()
+        _check(lib.sparsh_bench_comm(self._h, {"halo": 0, "allreduce": 1, "allgather": 2}[what], level, reps, C.byref(sec)))
+        return sec.value
 
     def level_kernel(self, level):
         """Name of the kernel the SpMV-type operations of this level launch under the current config."""

@@ -235,6 +235,14 @@ const char *sparsh_level_kernel(sparsh_handle h, int level)
     return c.kind == 1 ? "csr_wave_kernel" : "csr_block_kernel";
 }
 
+int sparsh_bench_comm(sparsh_handle h, int what, int level, int reps, double *avg_seconds)
+{
+    REQUIRE_READY(h);
+    if (!avg_seconds) return fail(SPARSH_EINVAL, "null output");
+    *avg_seconds = h->eng->bench_comm(what, level, reps);
+    return SPARSH_OK;
+}
+
 int sparsh_set_const_slots(int enable)
 {
     kernel_config().const_slots = enable != 0;

@@ -685,6 +685,34 @@ bool Engine::halo(const DevPlan &p, double *vec)
     return true;
 }
 
+double Engine::bench_comm(int what, int level, int reps)
+{
+    if (!dist_ || reps <= 0 || level < 0 || level >= (int)lev_.size()) return -1.0;
+    DevLevel &L = lev_[level];
+    if (what == 0 && L.replicated) return -1.0;
+    if (what == 2 && (repl_level_ <= 0 || repl_level_ >= (int)lev_.size())) return -1.0;
+    auto step = [&]() {
+        if (what == 0) return comm_->exchange(L.planA, L.x, st_);
+        if (what == 1) return comm_->allreduce_sum(scal_ + S_SUM0, 2, st_);
+        return comm_->allgather(lev_[repl_level_].r, gather_part_, st_);  // r of that level is scratch here
+    };
+    for (int i = 0; i < 3; ++i)
+        if (!step()) return -1.0;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, st_);
+    bool ok = true;
+    for (int i = 0; i < reps && ok; ++i) ok = step();
+    (void)hipEventRecord(e1, st_);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return ok ? ms * 1e-3 / reps : -1.0;
+}
+
 int Engine::apply_A(DevLevel &L, CsrOp op, CsrArgs a)
 {
     double *xin = const_cast<double *>(a.x);

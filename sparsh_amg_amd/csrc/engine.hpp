@@ -70,6 +70,10 @@ public:
     int nlevels() const { return (int)lev_.size(); }
     const HostHierarchy &host() const { return H_; }
     const sparsh_params &params() const { return prm_; }
+    // average seconds of one communication step alone (collective: every rank calls it): what = 0 halo
+    // exchange of level `level`'s operator, 1 the 16-byte all-reduce of the fused scalars, 2 the
+    // all-gather at the partitioned -> replicated boundary.  -1 when the step does not exist.
+    double bench_comm(int what, int level, int reps);
     hipStream_t stream() const { return st_; }
     const DevLevel &level(int l) const { return lev_[l]; }
     int n0() const { return A0_.nrow; }

@@ -29,11 +29,13 @@ def run_ranks(rp, ci, v, b, G, method, overlap=False, **kw):
                 A.set_overlap(True)
             lo, hi, rep = A.local_range(0)
             x = np.zeros(hi - lo)
-            if method == "vcycle3":
+            if method in ("vcycle3", "comm"):
                 h, rc = A.vcycle(b[lo:hi].copy(), x, iterations=3)
             else:
                 h, rc = A.solve(method, b[lo:hi].copy(), x)
             out[r] = (lo, hi, rep, x, h, rc, [A.local_range(l) for l in range(A.nlevels)], A.level_format(0)[0])
+            if method == "comm":  # the communication micro-benchmarks are collective calls too
+                out[r] = out[r] + ((A.bench_comm("halo", 0, 3), A.bench_comm("allreduce", 0, 3), A.bench_comm("allgather", 0, 3)),)
             A.close()
         except Exception as e:  # noqa: BLE001
             errs.append((r, repr(e)))
@@ -165,3 +167,21 @@ def test_overlapped_exchange_same_results(G):
     x0 = np.concatenate([r[3] for r in sorted(hb, key=lambda t: t[0])])
     x1 = np.concatenate([r[3] for r in sorted(ho, key=lambda t: t[0])])
     assert np.linalg.norm(x0 - x1) <= 1e-10 * np.linalg.norm(x0)
+
+
+def test_comm_microbenchmarks_are_collective_and_harmless():
+    """sparsh_bench_comm (bench.py's multi-GPU diagnostics): every virtual rank times the halo exchange,
+    the scalar all-reduce and the boundary all-gather; the calls return and a later solve is unaffected."""
+    rp, ci, v = problems.poisson3d(30)
+    n = len(rp) - 1
+    b = np.ones(n)
+    res = run_ranks(rp, ci, v, b, 3, "comm", replicate_rows=2000)
+    for r in res:
+        t_halo, t_red, t_gather = r[8]
+        assert t_halo > 0 and t_red > 0 and t_gather > 0, r[8]
+    ref = run_ranks(rp, ci, v, b, 3, "vcycle3", replicate_rows=2000)
+    for r, q in zip(res, ref):
+        assert np.array_equal(r[3], q[3]) and np.array_equal(r[4], q[4])
+    A1 = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET))
+    assert A1.bench_comm("halo", 0, 3) == -1.0   # single GPU: no such step
+    A1.close()
