@@ -89,6 +89,8 @@ def main():
 
     if os.environ.get("SPARSH_BENCH_KCFG"):  # A/B runs: "kind,vec,nt,remap" instead of the per-operator policy
         sa.set_kernel_config(*[int(t) for t in os.environ["SPARSH_BENCH_KCFG"].split(",")])
+    if os.environ.get("SPARSH_BENCH_NO_FOLD", "0") == "1":  # profile the general layout (what a variable-coefficient operator gets)
+        sa.set_const_slots(False)
     if sa.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the HIP path is the only compute path")
 
@@ -228,7 +230,7 @@ def main():
         achieved = jac_bytes / avg / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and os.environ.get("SPARSH_BENCH_NO_FOLD", "0") != "1":  # the PMC file describes the default path
             try:
                 traffic = json.load(open(pmc)).get("jacobi_fine_bytes_per_launch")
             except Exception:
