@@ -59,6 +59,11 @@ def main():
     res["C3D_poisson3d_216"] = run("C3D", *problems.poisson3d(216), ["amg", "pcg"])
     # nu = 6 sweeps: what the reference's GPU path effectively runs (smooth_iter without the +1 of the CPU path)
     res["C3D_poisson3d_216_nu6"] = run("C3D nu=6", *problems.poisson3d(216), ["amg", "pcg"], sweeps=6)
+    # Beck's classical C/F interpolation instead of HEM aggregation (general multi-entry P and R, denser
+    # coarse operators: CSR-stream / sliced-ELL kernels on the coarse levels)
+    res["C3D_poisson3d_100_beck"] = run("C3D 100^3 Beck", *problems.poisson3d(100), ["amg", "pcg"], coarsening=1)
+    res["C2D_poisson2d_1000_beck"] = run("C2D Beck", *problems.poisson2d(1000), ["amg", "pcg"], coarsening=1)
+    res["C3D_poisson3d_216_beck"] = run("C3D 216^3 Beck", *problems.poisson3d(216), ["amg", "pcg"], coarsening=1)
     mtx = os.environ.get("SPARSH_MTX")  # e.g. SuiteSparse parabolic_fem.mtx when it is on the box
     if mtx and os.path.exists(mtx):
         res["CU_" + os.path.basename(mtx)] = run("CU file", *problems.read_matrix_market(mtx), ["pbicg", "pcg"])
