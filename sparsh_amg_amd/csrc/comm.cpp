@@ -59,12 +59,16 @@ public:
     }
     bool allgather(double *full, const Partition &part, hipStream_t st) override
     {
-        // ranges differ in length: one broadcast per owner, grouped
+        // ranges differ in length, and on a full xGMI mesh every pair has its own link: one grouped
+        // set of point-to-point transfers (my range to every peer, every peer's range from it), in place
+        // -- the same primitives, in the same kind of group, as the halo exchange
+        const int mylo = part.lo(rank), mycnt = part.hi(rank) - mylo;
         if (!ok(ncclGroupStart(), "ncclGroupStart")) return false;
-        for (int r = 0; r < size; ++r) {
-            const int lo = part.lo(r), cnt = part.hi(r) - lo;
-            if (cnt <= 0) continue;
-            if (!ok(ncclBroadcast(full + lo, full + lo, (size_t)cnt, ncclDouble, r, comm, st), "ncclBroadcast")) return false;
+        for (int q = 0; q < size; ++q) {
+            if (q == rank) continue;
+            const int lo = part.lo(q), cnt = part.hi(q) - lo;
+            if (mycnt > 0 && !ok(ncclSend(full + mylo, (size_t)mycnt, ncclDouble, q, comm, st), "ncclSend")) return false;
+            if (cnt > 0 && !ok(ncclRecv(full + lo, (size_t)cnt, ncclDouble, q, comm, st), "ncclRecv")) return false;
         }
         return ok(ncclGroupEnd(), "ncclGroupEnd");
     }
