@@ -188,7 +188,8 @@ int sparsh_level_format(sparsh_handle h, int level, int *kind, long *stored_entr
     const KernelConfig &c = kernel_config();
     int k = 0;
     long e = A.nnz;
-    if (c.kind == 3 && A.has_sdia()) {
+    const bool small_prefers_ell = A.sell_val && A.nrow < 65536 && !(c.table && A.sd_tmask);  // as in launch_csr_tagged
+    if (c.kind == 3 && A.has_sdia() && !small_prefers_ell) {
         k = 3;
         e = A.sd_vblocks * 64;  // values actually stored: constant slots own no block
     } else if (c.kind >= 2 && A.sell_val) {
@@ -230,7 +231,8 @@ const char *sparsh_level_kernel(sparsh_handle h, int level)
     if (!h || !h->eng || !h->eng->ready() || level < 0 || level >= (int)h->eng->host().levels.size()) return "";
     const DevCsr &A = h->eng->level(level).A;
     const KernelConfig &c = kernel_config();
-    if (c.kind == 3 && A.has_sdia()) return (c.table && A.sd_tmask) ? "sdia_tab_kernel" : "sdia_kernel";
+    if (c.kind == 3 && A.has_sdia() && c.table && A.sd_tmask) return "sdia_tab_kernel";
+    if (c.kind == 3 && A.has_sdia() && !(A.sell_val && A.nrow < 65536)) return "sdia_kernel";
     if (c.kind >= 2 && A.sell_val) return "sell_kernel";
     return c.kind == 1 ? "csr_wave_kernel" : "csr_block_kernel";
 }

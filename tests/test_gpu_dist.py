@@ -106,8 +106,9 @@ def test_fixed_cycles_bitwise_rows():
     res = run_ranks(rp, ci, v, b, 3, "vcycle3", replicate_rows=2000)
     x = np.concatenate([r[3] for r in sorted(res, key=lambda t: t[0])])
     assert np.array_equal(x, x1)
-    # rank-local blocks of a stencil operator keep the sliced-diagonal layout (halo columns included)
-    assert all(r[7] == 3 for r in res), [r[7] for r in res]
+    # rank-local blocks of a stencil operator keep a sliced layout, halo columns included: sliced
+    # diagonals, or sliced ELL for a small block whose halo slices leave it without a stencil table
+    assert all(r[7] in (2, 3) for r in res), [r[7] for r in res]
 
 
 def test_everything_replicated_small_problem():
@@ -157,7 +158,7 @@ def test_overlapped_exchange_same_results(G):
     xb = np.concatenate([r[3] for r in sorted(base, key=lambda t: t[0])])
     xo = np.concatenate([r[3] for r in sorted(over, key=lambda t: t[0])])
     assert np.array_equal(xb, xo)
-    assert all(r[7] == 3 for r in over)  # sliced-diagonal blocks: the overlap path is really taken
+    assert all(r[7] in (2, 3) for r in over)  # sliced blocks: the overlap path is really taken
     hb = run_ranks(rp, ci, v, b, G, "pcg", replicate_rows=3000)
     ho = run_ranks(rp, ci, v, b, G, "pcg", overlap=True, replicate_rows=3000)
     # the fused reductions add their partials in a different order (interior groups, then boundary

@@ -339,7 +339,7 @@ def test_constant_slot_folding_bitwise():
     dpos = np.flatnonzero(ci3 == rows3)
     v3p[dpos[[5, 7000, 7001, 64000, 110000]]] += np.array([0.5, 0.25, 1.0, 2.0, 0.125])
     v3p[dpos[30000] + 1] = -0.75
-    for name, (rp, ci, v) in (("p3d", (rp3, ci3, v3)), ("p3d_perturbed", (rp3, ci3, v3p)), ("mixed", _mixed_coefficients(200))):
+    for name, (rp, ci, v) in (("p3d", (rp3, ci3, v3)), ("p3d_perturbed", (rp3, ci3, v3p)), ("mixed", _mixed_coefficients(300))):
         n = len(rp) - 1
         A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET, max_levels=2))
         try:
