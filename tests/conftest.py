@@ -33,9 +33,25 @@ def golden():
         return json.load(f)
 
 
+C0_FIXTURE = os.path.join(ROOT, "tests", "golden", "c0_matrix.npz")  # data fixture made by tests/golden/make_c0_fixture.py
+
+
 @pytest.fixture(scope="session")
 def have_c0():
+    """The reference tree itself (build container only); the C0 *data* travels as C0_FIXTURE."""
     return os.path.exists(C0_MATRIX) and os.path.exists(C0_RHS)
+
+
+def load_c0():
+    """BASELINE.json configs[0]: (rowptr, colindex, val, b) of the reference's bundled matrix."""
+    z = np.load(C0_FIXTURE)
+    return (np.ascontiguousarray(z["rowptr"], dtype=np.int32), np.ascontiguousarray(z["colindex"], dtype=np.int32),
+            np.ascontiguousarray(z["val"], dtype=np.float64), np.ascontiguousarray(z["b"], dtype=np.float64))
+
+
+@pytest.fixture(scope="session")
+def c0_arrays():
+    return load_c0()
 
 
 def rel_close(a, b, rtol):

@@ -49,10 +49,18 @@ def test_hierarchy_matches_oracle_beck(gen, kw):
         assert abs(S - O).max() <= 1e-13 * abs(O).max()
 
 
-def test_c0_hierarchy_golden(have_c0, golden):
+def test_c0_readcoo_equals_fixture(have_c0, c0_arrays):
     if not have_c0:
-        pytest.skip("bundled matrix lives in /root/reference (build container only)")
+        pytest.skip("/root/reference exists in the build container only")
     A, b = sa.readcoo(C0_MATRIX, C0_RHS)
+    rp, ci, v = A.rowptr, A.colindex, A.val
+    assert np.array_equal(rp, c0_arrays[0]) and np.array_equal(ci, c0_arrays[1])
+    assert np.array_equal(v, c0_arrays[2]) and np.array_equal(b, c0_arrays[3])
+
+
+def test_c0_hierarchy_golden(c0_arrays, golden):
+    rp, ci, v, b = c0_arrays
+    A = sa.sp_matrix_mg(rp, ci, v)
     A.setup(sa.default_params(print_setup=0), host_only=True)
     g = golden["C0"]["hem"]
     assert [A.level_info(l)["nrow"] for l in range(A.nlevels)] == g["levels_nrow"]

@@ -19,10 +19,20 @@ def _check_hist(h, ref, scale=1.0):
 
 
 @pytest.fixture(scope="module")
-def c0(have_c0):
+def c0(c0_arrays):
+    rp, ci, v, b = c0_arrays
+    return oracle.Csr(rp, ci, v), b
+
+
+def test_c0_fixture_is_the_reference_file(have_c0, c0_arrays):
+    """tests/golden/c0_matrix.npz holds exactly what the reference's reader makes of its bundled
+    files (checked wherever /root/reference exists; the fixture alone travels to the GPU box)."""
     if not have_c0:
-        pytest.skip("bundled matrix lives in /root/reference (build container only)")
-    return oracle.readcoo(C0_MATRIX, C0_RHS)
+        pytest.skip("/root/reference exists in the build container only")
+    A, b = oracle.readcoo(C0_MATRIX, C0_RHS)
+    rp, ci, v = A.arrays()
+    assert np.array_equal(rp, c0_arrays[0]) and np.array_equal(ci, c0_arrays[1])
+    assert np.array_equal(v, c0_arrays[2]) and np.array_equal(b, c0_arrays[3])
 
 
 def test_c0_readcoo_shape(c0):
