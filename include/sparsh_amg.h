@@ -51,10 +51,12 @@ typedef struct sparsh_params {
     int coarsening;     /* 0 = HEM pairwise aggregation (default, src/AMG_phases.cpp:60),
                            1 = Beck (src/AMG_phases.cpp:63)                    [SPARSH_COARSENING=hem|beck] */
     int max_iter;       /* guard the reference lacks: cap on cycles/iterations [SPARSH_MAXIT]   */
-    int coarse_limit;   /* largest coarsest level solved directly on the device (explicit
-                           inverse, one GEMV per V-cycle).  If max_levels leaves a coarsest level
-                           above it, coarsening continues past max_levels (documented deviation
-                           from the reference, which hands any size to PARDISO).  [SPARSH_COARSE_LIMIT] */
+    int coarse_limit;   /* largest coarsest level max_levels may leave for the device direct solver
+                           (default 40000: up to ~1.3 M rows the hierarchy is exactly the reference's,
+                           src/AMG_phases.cpp:51,77,89).  If max_levels would leave more, coarsening
+                           continues by the same rule until <= limit_upper rows (documented deviation
+                           from the reference, which hands any size to PARDISO; 1<<30 disables it).
+                                                                               [SPARSH_COARSE_LIMIT] */
     int host_threads;   /* OpenMP threads for the host setup (0 = all)        [SPARSH_THREADS] */
     int device;         /* HIP device ordinal (-1 = current / LOCAL_RANK)                     */
     int print_setup;    /* print_setup_phase_details = 1                       [SPARSH_PRINT]   */
@@ -70,6 +72,10 @@ typedef struct sparsh_params {
                            the CG recurrences, residuals and the stopping test stay fp64.  Not a parity
                            mode: a different (cheaper) preconditioner, same solution to tol.
                                                                                [SPARSH_PRECOND_FP32] */
+    int dense_limit;    /* coarsest levels up to this many rows are solved with an explicit dense inverse
+                           (one GEMV per V-cycle); larger ones with the block-tridiagonal factorisation of
+                           the RCM-ordered operator, factored and applied on the device (csrc/coarse.cpp).
+                           Default 8192.                                       [SPARSH_DENSE_LIMIT] */
 } sparsh_params;
 
 typedef struct sparsh_handle_s *sparsh_handle;
@@ -144,8 +150,13 @@ int sparsh_level_info(sparsh_handle h, int level, int *nrow, int *nnz, int *p_nc
 /* which: 0 = A_level, 1 = P_level (level < last).  Buffers sized from sparsh_level_info. */
 int sparsh_level_csr(sparsh_handle h, int level, int which, int *rowptr, int *colindex, double *val);
 /* explicit inverse of the coarsest operator, row-major nL x nL (what the device GEMV applies in
- * place of Direct_Solver_Pardiso_solve); available after sparsh_setup_host */
+ * place of Direct_Solver_Pardiso_solve); available after sparsh_setup_host when the coarsest level
+ * has at most dense_limit rows */
 int sparsh_coarse_inverse(sparsh_handle h, double *inv);
+/* form of the coarsest-level direct solver: info6 = {rows, dense (1) or block-tridiagonal (0), block size,
+ * number of blocks, RCM bandwidth, hierarchy extended past max_levels (1/0)}; *bytes = HBM held by the
+ * factors.  After sparsh_setup (block fields are 0 for the dense form or before the device setup). */
+int sparsh_coarse_info(sparsh_handle h, int *info6, long *bytes);
 double sparsh_setup_seconds(sparsh_handle h);
 
 /* AMG_solver::AMG_solve_jacobi(b, x, iterations) (src/AMG_phases.cpp:151-230) ==

@@ -57,6 +57,7 @@ class Params(C.Structure):
         ("use_graph", C.c_int),
         ("replicate_rows", C.c_int),
         ("precond_fp32", C.c_int),
+        ("dense_limit", C.c_int),
     ]
 
 
@@ -90,6 +91,7 @@ def _load():
         "sparsh_level_info": (C.c_int, [H, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p]),
         "sparsh_level_csr": (C.c_int, [H, C.c_int, C.c_int, c_int_p, c_int_p, c_dbl_p]),
         "sparsh_coarse_inverse": (C.c_int, [H, c_dbl_p]),
+        "sparsh_coarse_info": (C.c_int, [H, c_int_p, C.POINTER(C.c_long)]),
         "sparsh_setup_seconds": (C.c_double, [H]),
         "sparsh_vcycle": (C.c_int, [H, c_dbl_p, c_dbl_p, C.c_int, c_dbl_p, C.c_int, c_int_p]),
         "sparsh_vcycle_dev": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int, c_dbl_p, C.c_int, c_int_p]),
@@ -303,6 +305,14 @@ class sp_matrix_mg:
         inv = np.zeros((n, n))
         _check(lib.sparsh_coarse_inverse(self._h, _dp(inv)))
         return inv
+
+    def coarse_info(self):
+        """Form of the coarsest-level direct solver (dense inverse or block-tridiagonal factors)."""
+        info = (C.c_int * 6)()
+        nbytes = C.c_long(0)
+        _check(lib.sparsh_coarse_info(self._h, info, C.byref(nbytes)))
+        return {"rows": info[0], "dense": bool(info[1]), "block": info[2], "nblocks": info[3], "bandwidth": info[4],
+                "extended": bool(info[5]), "bytes": nbytes.value}
 
     # -- multi-GPU -------------------------------------------------------------------------
     def comm_init_rccl(self, unique_id: bytes, rank: int, nranks: int):

@@ -6,10 +6,12 @@
 #include <cmath>
 #include <cstdlib>
 #include <iostream>
+#include <string>
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
 
+#include "coarse.hpp"
 #include "host_setup.hpp"
 #include "kernels.hpp"
 #include "../../include/AMG_coarse_level_solver.hpp"
@@ -306,7 +308,7 @@ void reorder_prolongator(sp_matrix_mg &, sp_matrix_mg *&) { not_in_build("reorde
 
 namespace {
 struct DirectImpl {
-    double *inv = nullptr;
+    CoarseSolver solver;
     int n = 0;
 };
 }  // namespace
@@ -314,19 +316,27 @@ struct DirectImpl {
 Direct_Solver_Pardiso::Direct_Solver_Pardiso(sp_matrix_mg &A)
 {
     n = A.nrow;
-    std::vector<double> inv;
-    if (!sparse_inverse(HostCsr::alias(A.nrow, A.ncol, A.rowptr, A.colindex, A.val), inv)) {
-        std::cout << "\nERROR during symbolic factorization: singular matrix" << std::endl;
-        error = 1;
-        std::exit(1);  // the reference exits on a PARDISO error (src/AMG_coarse_level_solver.cpp:53-57)
-    }
+    const HostCsr H = HostCsr::alias(A.nrow, A.ncol, A.rowptr, A.colindex, A.val);
     DirectImpl *d = new DirectImpl();
     d->n = n;
-    if (hipMalloc(reinterpret_cast<void **>(&d->inv), (size_t)n * n * sizeof(double)) != hipSuccess) {
-        std::cout << "sparsh: device allocation failed (or no HIP device: there is no CPU fallback)" << std::endl;
+    std::string err;
+    bool ok;
+    if (n <= 8192) {  // explicit inverse, one GEMV per solve
+        std::vector<double> inv;
+        if (!sparse_inverse(H, inv)) {
+            std::cout << "\nERROR during symbolic factorization: singular matrix" << std::endl;
+            error = 1;
+            std::exit(1);  // the reference exits on a PARDISO error (src/AMG_coarse_level_solver.cpp:53-57)
+        }
+        ok = d->solver.setup_dense(n, inv.data(), err);
+    } else {  // block-tridiagonal factors, built on the device
+        ok = d->solver.setup_bt(H, nullptr, err);
+    }
+    if (!ok) {
+        std::cout << "sparsh: coarse direct solver failed (" << err << "); without a HIP device there is no CPU fallback" << std::endl;
+        error = 1;
         std::exit(1);
     }
-    (void)hipMemcpy(d->inv, inv.data(), (size_t)n * n * sizeof(double), hipMemcpyHostToDevice);
     impl_ = d;
 }
 
@@ -335,7 +345,7 @@ void Direct_Solver_Pardiso::Direct_Solver_Pardiso_solve(double *&b, double *&x)
     DirectImpl *d = static_cast<DirectImpl *>(impl_);
     if (!d) return;
     DevBuf db((size_t)n, b), dx((size_t)n);
-    launch_gemv(n, d->inv, db.p, dx.p, nullptr);
+    d->solver.solve(db.p, dx.p, nullptr);
     dx.get(x, (size_t)n);
 }
 
@@ -343,7 +353,6 @@ Direct_Solver_Pardiso::~Direct_Solver_Pardiso()
 {
     DirectImpl *d = static_cast<DirectImpl *>(impl_);
     if (d) {
-        (void)hipFree(d->inv);
         delete d;
         impl_ = nullptr;
     }

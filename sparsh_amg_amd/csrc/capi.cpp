@@ -104,7 +104,8 @@ void sparsh_default_params(sparsh_params *p)
     p->coarsening = 0;
     if (const char *c = std::getenv("SPARSH_COARSENING")) p->coarsening = (std::strcmp(c, "beck") == 0) ? 1 : 0;
     p->max_iter = env_int("SPARSH_MAXIT", 100000);
-    p->coarse_limit = env_int("SPARSH_COARSE_LIMIT", 8192);
+    p->coarse_limit = env_int("SPARSH_COARSE_LIMIT", 40000);
+    p->dense_limit = env_int("SPARSH_DENSE_LIMIT", 8192);
     p->host_threads = env_int("SPARSH_THREADS", 0);
     p->device = -1;
     if (const char *lr = std::getenv("LOCAL_RANK")) p->device = std::atoi(lr);
@@ -286,8 +287,27 @@ int sparsh_coarse_inverse(sparsh_handle h, double *inv)
 {
     REQUIRE_HOST(h);
     const HostHierarchy &H = h->eng->host();
+    if (!H.coarse_dense) return fail(SPARSH_ESTATE, "the coarsest level is above dense_limit: it is factored on the device in block-tridiagonal form, no dense inverse exists");
     if (H.coarse_inverse.empty()) return fail(SPARSH_ESTATE, "host copy of the inverse was released by sparsh_setup; use sparsh_setup_host");
     std::memcpy(inv, H.coarse_inverse.data(), sizeof(double) * (size_t)H.nL * H.nL);
+    return SPARSH_OK;
+}
+
+int sparsh_coarse_info(sparsh_handle h, int *info6, long *bytes)
+{
+    REQUIRE_HOST(h);
+    const HostHierarchy &H = h->eng->host();
+    const CoarseSolver &c = h->eng->coarse();
+    const bool bt = c.ready() && !c.dense();
+    if (info6) {
+        info6[0] = H.nL;
+        info6[1] = H.coarse_dense ? 1 : 0;
+        info6[2] = bt ? c.block() : 0;
+        info6[3] = bt ? c.nblocks() : 0;
+        info6[4] = bt ? c.bandwidth() : 0;
+        info6[5] = H.extended ? 1 : 0;
+    }
+    if (bytes) *bytes = c.ready() ? (long)c.bytes() : 0;
     return SPARSH_OK;
 }
 

@@ -1,0 +1,258 @@
+// coarse.cpp -- host side of the device coarse direct solver (see coarse.hpp).
+#include "coarse.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+
+#include "kernels.hpp"
+
+namespace sparsh {
+
+namespace {
+
+HostCsr make_csr(int n, std::vector<int> &&rp, std::vector<int> &&ci, std::vector<double> &&v)
+{
+    HostCsr M;
+    M.nrow = M.ncol = n;
+    M.rp_store = std::move(rp);
+    M.col_store = std::move(ci);
+    M.val_store = std::move(v);
+    M.adopt();
+    return M;
+}
+
+}  // namespace
+
+bool bt_make_plan(const HostCsr &A, int target_blocks, int max_block, BtPlan &P, std::string &err)
+{
+    const int n = A.nrow;
+    P = BtPlan();
+    P.n = n;
+    P.perm = rcm_order(A);
+    std::vector<int> inv((size_t)n);
+    for (int i = 0; i < n; ++i) inv[P.perm[i]] = i;
+    int bw = 0;
+    for (int i = 0; i < n; ++i)
+        for (int j = A.rowptr[i]; j < A.rowptr[i + 1]; ++j) bw = std::max(bw, std::abs(inv[i] - inv[A.col[j]]));
+    P.bw = bw;
+    auto up64 = [](int x) { return (x + 63) / 64 * 64; };
+    // any B >= bandwidth makes the permuted operator block tridiagonal.  Narrow-band operators (2D
+    // grids) take wider blocks, up to 1024, so the chain of dependent steps stays short.
+    int B = std::max(up64(std::max(bw, 1)), std::min(up64((n + target_blocks - 1) / std::max(1, target_blocks)), 1024));
+    if (B > max_block) {
+        err = "coarsest level too wide for the block-tridiagonal device solve: bandwidth " + std::to_string(bw) + " after RCM (limit " +
+              std::to_string(max_block) + "); lower coarse_limit so the hierarchy is extended instead";
+        return false;
+    }
+    P.B = B;
+    P.nb = (n + B - 1) / B;
+    P.mid = P.nb / 2;
+    // permuted rows with sorted columns, split into diag / out / in pieces
+    std::vector<int> rp[3];
+    std::vector<int> ci[3];
+    std::vector<double> v[3];
+    for (int q = 0; q < 3; ++q) rp[q].assign((size_t)n + 1, 0);
+    std::vector<std::pair<int, double>> row;
+    auto piece_of = [&](int r, int c) {  // 0 diag, 1 out, 2 in
+        const int br = r / B, bc = c / B;
+        if (bc == br) return 0;
+        if (br == P.mid) return 1;
+        const int outer = br < P.mid ? br - 1 : br + 1;
+        return bc == outer ? 1 : 2;
+    };
+    for (int r = 0; r < n; ++r) {
+        const int o = P.perm[r];
+        row.clear();
+        for (int j = A.rowptr[o]; j < A.rowptr[o + 1]; ++j) row.emplace_back(inv[A.col[j]], A.val[j]);
+        std::sort(row.begin(), row.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+        for (const auto &e : row) {
+            const int q = piece_of(r, e.first);
+            ci[q].push_back(e.first);
+            v[q].push_back(e.second);
+        }
+        for (int q = 0; q < 3; ++q) rp[q][(size_t)r + 1] = (int)ci[q].size();
+    }
+    P.diag = make_csr(n, std::move(rp[0]), std::move(ci[0]), std::move(v[0]));
+    P.out = make_csr(n, std::move(rp[1]), std::move(ci[1]), std::move(v[1]));
+    P.in = make_csr(n, std::move(rp[2]), std::move(ci[2]), std::move(v[2]));
+    P.inT = transpose(P.in);
+    return true;
+}
+
+void CoarseSolver::release()
+{
+    for (void *p : allocs_) (void)hipFree(p);
+    allocs_.clear();
+    inv_ = sinv_ = z_ = nullptr;
+    perm_ = nullptr;
+    out_ = in_ = BtDevCsr();
+    steps_.clear();
+    n_ = 0;
+}
+
+namespace {
+
+template <class T>
+T *dev_alloc(std::vector<void *> &allocs, size_t count, std::string &err)
+{
+    void *p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) {
+        err = "hipMalloc of " + std::to_string(count * sizeof(T)) + " bytes failed (coarse direct solver)";
+        return nullptr;
+    }
+    allocs.push_back(p);
+    return static_cast<T *>(p);
+}
+
+template <class T>
+T *dev_upload(std::vector<void *> &allocs, const T *src, size_t count, std::string &err)
+{
+    T *d = dev_alloc<T>(allocs, count, err);
+    if (d && count && hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
+        err = "hipMemcpy H2D failed (coarse direct solver)";
+        return nullptr;
+    }
+    return d;
+}
+
+bool upload_piece(std::vector<void *> &allocs, const HostCsr &M, BtDevCsr &D, std::string &err)
+{
+    D.rp = dev_upload(allocs, M.rowptr, (size_t)M.nrow + 1, err);
+    D.ci = dev_upload(allocs, M.col, (size_t)M.nnz(), err);
+    D.v = dev_upload(allocs, M.val, (size_t)M.nnz(), err);
+    return D.rp && D.ci && D.v;
+}
+
+}  // namespace
+
+bool CoarseSolver::setup_dense(int n, const double *inv_host, std::string &err)
+{
+    release();
+    inv_ = dev_upload(allocs_, inv_host, (size_t)n * n, err);
+    if (!inv_) return false;
+    n_ = n;
+    dense_ = true;
+    return true;
+}
+
+bool CoarseSolver::setup_bt(const HostCsr &A, hipStream_t st, std::string &err, int *why_failed)
+{
+    release();
+    int why_local = 0;
+    int &why = why_failed ? *why_failed : why_local;
+    why = 3;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!bt_make_plan(A, 32, 6144, plan_, err)) {
+        why = 1;
+        return false;
+    }
+    const BtPlan &P = plan_;
+    const int n = P.n, B = P.B, nb = P.nb, mid = P.mid;
+    BtDevCsr diag, inT;
+    std::vector<void *> tmp;  // setup-only device buffers
+    auto drop_tmp = [&]() {
+        for (void *p : tmp) (void)hipFree(p);
+        tmp.clear();
+    };
+    bool ok = upload_piece(allocs_, P.out, out_, err) && upload_piece(allocs_, P.in, in_, err) && upload_piece(tmp, P.diag, diag, err) &&
+              upload_piece(tmp, P.inT, inT, err);
+    perm_ = ok ? dev_upload(allocs_, P.perm.data(), (size_t)n, err) : nullptr;
+    z_ = ok ? dev_alloc<double>(allocs_, (size_t)n, err) : nullptr;
+    sinv_ = ok ? dev_alloc<double>(allocs_, (size_t)nb * B * B, err) : nullptr;
+    double *S = ok ? dev_alloc<double>(tmp, (size_t)B * B, err) : nullptr;
+    double *S2 = ok ? dev_alloc<double>(tmp, (size_t)B * B, err) : nullptr;
+    double *c0 = ok ? dev_alloc<double>(tmp, (size_t)B, err) : nullptr;
+    double *c1 = ok ? dev_alloc<double>(tmp, (size_t)B, err) : nullptr;
+    int *piv = ok ? dev_alloc<int>(tmp, (size_t)B, err) : nullptr;
+    int *cmap = ok ? dev_alloc<int>(tmp, (size_t)B, err) : nullptr;
+    int *sing = ok ? dev_alloc<int>(tmp, 1, err) : nullptr;
+    if (!(ok && perm_ && z_ && sinv_ && S && S2 && c0 && c1 && piv && cmap && sing)) {
+        drop_tmp();
+        release();
+        return false;
+    }
+    (void)hipMemsetAsync(sinv_, 0, (size_t)nb * B * B * sizeof(double), st);
+    (void)hipMemsetAsync(z_, 0, (size_t)n * sizeof(double), st);
+    (void)hipMemsetAsync(sing, 0, sizeof(int), st);
+    const size_t bstride = (size_t)B * B;
+    auto factor_block = [&](int i, int o1, int o2) {
+        const int r0 = i * B, bs = P.block_rows(i);
+        bt_launch_diag(r0, bs, B, diag.rp, diag.ci, diag.v, S, st);
+        for (int o : {o1, o2})
+            if (o >= 0 && o < nb) bt_launch_schur(r0, bs, o * B, P.block_rows(o), B, out_, inT, sinv_ + (size_t)o * bstride, S, st);
+        bt_launch_invert(bs, B, S, S2, c0, c1, piv, cmap, sing, sinv_ + (size_t)i * bstride, st);
+    };
+    for (int i = 0; i < mid; ++i) factor_block(i, i - 1, -1);          // top chain
+    for (int i = nb - 1; i > mid; --i) factor_block(i, i + 1, -1);     // bottom chain
+    factor_block(mid, mid - 1, mid + 1);                                // middle block
+    int sing_h = 0;
+    const bool copied = hipMemcpyAsync(&sing_h, sing, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess;
+    const hipError_t e = hipStreamSynchronize(st);
+    drop_tmp();
+    if (!copied || e != hipSuccess) {
+        err = std::string("device factorisation of the coarsest level failed: ") + hipGetErrorString(e);
+        release();
+        return false;
+    }
+    if (sing_h) {
+        why = 2;
+        err = "coarsest-level matrix is singular (zero pivot in a diagonal block of the block-tridiagonal factorisation)";
+        release();
+        return false;
+    }
+    // schedule of a solve: inward steps pair block s of the top chain with block nb-1-s of the bottom
+    // chain, then the middle block (final), then the same pairs outward
+    auto add = [&](std::vector<int> blks, int mode, int final_) {
+        Step s{};
+        s.nblk = (int)blks.size();
+        for (int q = 0; q < s.nblk; ++q) {
+            s.blk[q] = blks[q];
+            s.r0[q] = blks[q] * B;
+            s.bs[q] = P.block_rows(blks[q]);
+        }
+        s.mode = mode;
+        s.final_ = final_;
+        steps_.push_back(s);
+    };
+    const int ntop = mid, nbot = nb - 1 - mid;
+    for (int s = 0; s < std::max(ntop, nbot); ++s) {
+        std::vector<int> blks;
+        if (s < ntop) blks.push_back(s);
+        if (s < nbot) blks.push_back(nb - 1 - s);
+        add(blks, 0, 0);
+    }
+    add({mid}, 0, 1);
+    for (int s = std::max(ntop, nbot) - 1; s >= 0; --s) {
+        // outward: distance from the middle grows; pair top block mid-1-t with bottom block mid+1+t
+        const int t = std::max(ntop, nbot) - 1 - s;
+        std::vector<int> blks;
+        if (mid - 1 - t >= 0) blks.push_back(mid - 1 - t);
+        if (mid + 1 + t < nb) blks.push_back(mid + 1 + t);
+        if (!blks.empty()) add(blks, 1, 1);
+    }
+    // the host pieces are no longer needed (sizes stay in plan_)
+    plan_.diag = plan_.out = plan_.in = plan_.inT = HostCsr();
+    n_ = n;
+    dense_ = false;
+    why = 0;
+    factor_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return true;
+}
+
+void CoarseSolver::solve(const double *b, double *x, hipStream_t st) const
+{
+    if (n_ <= 0) return;
+    if (dense_) {
+        launch_gemv(n_, inv_, b, x, st);
+        return;
+    }
+    const size_t bstride = (size_t)plan_.B * plan_.B;
+    for (const Step &s : steps_)
+        bt_launch_solve_step(s.r0, s.bs, s.blk, s.nblk, s.mode, s.final_, plan_.B, bstride, sinv_, perm_, s.mode == 0 ? out_ : in_, b, z_, x, st);
+}
+
+}  // namespace sparsh

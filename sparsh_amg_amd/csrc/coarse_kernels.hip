@@ -1,0 +1,333 @@
+// coarse_kernels.hip -- device kernels of the block-tridiagonal direct solver for large coarsest
+// levels (replaces Direct_Solver_Pardiso, src/AMG_coarse_level_solver.cpp:9-76, where the explicit
+// dense inverse would not fit: the reference's level1 = 6 policy hands N/32 rows to PARDISO).
+//
+// The coarsest operator, renumbered by reverse Cuthill-McKee, is block tridiagonal for any block
+// size B >= its bandwidth.  It is factored from both ends towards a middle block ("twisted"
+// block LU, pivoting inside the diagonal blocks):
+//     top chain     S_i = D_i - A[i,i-1] S_{i-1}^-1 A[i-1,i]        i = 0 .. mid-1
+//     bottom chain  S_i = D_i - A[i,i+1] S_{i+1}^-1 A[i+1,i]        i = nb-1 .. mid+1
+//     middle        S_m = D_m - A[m,m-1] S_{m-1}^-1 A[m-1,m] - A[m,m+1] S_{m+1}^-1 A[m+1,m]
+// and only the explicit inverses S_i^-1 (B x B, dense) are kept.  A solve is
+//     inward   z_i = S_i^-1 (b_i - A[i,outer] z_outer)              both chains at once, then the middle
+//     outward  z_i = z_i - S_i^-1 (A[i,inner] z_inner)              both chains at once
+// i.e. about nb sequential steps of one dense B x B GEMV (two per launch) plus a sparse product
+// with the off-diagonal blocks of the permuted operator.  Setup kernels: Schur-complement
+// assembly, Gauss-Jordan inversion with partial pivoting (one launch per pivot, ping-pong
+// buffers, the next pivot column's magnitudes produced by the previous step), column unscramble.
+// Everything is deterministic (no atomics).
+#include <hip/hip_runtime.h>
+
+#include "coarse.hpp"
+
+namespace sparsh {
+
+namespace {
+
+constexpr int kCB = 256;  // threads per workgroup
+
+__device__ __forceinline__ double wsum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// S (bs x bs, leading dimension ld) = dense copy of the diagonal block of the permuted operator:
+// rows [r0, r0+bs), entries with columns in the same range
+__global__ __launch_bounds__(kCB) void bt_diag_kernel(int r0, int bs, int ld, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                      const double *__restrict__ v, double *__restrict__ S)
+{
+    const int r = blockIdx.x;
+    double *row = S + (size_t)r * ld;
+    for (int j = threadIdx.x; j < bs; j += kCB) row[j] = 0.0;
+    __syncthreads();
+    const int g = r0 + r;
+    for (int j = rp[g] + threadIdx.x; j < rp[g + 1]; j += kCB) row[ci[j] - r0] = v[j];
+}
+
+// S -= A[i,o] Sinv_o A[o,i] for one neighbour block o.  One workgroup per row r of block i:
+//   T = sum_k A[r,k] Sinv_o[k,:]        (k over the entries of row r in block o: few)
+//   S[r,c] -= sum_m T[m] A[o*B+m, c]    (column c of A[o,i] = row c of the transposed piece)
+// out: CSR of the entries that couple a block to its outer neighbour(s); inT: CSR of the TRANSPOSE of
+// the entries that couple a block to its inner neighbour (row = column index of the entry).
+__global__ __launch_bounds__(kCB) void bt_schur_kernel(int r0, int bs, int o0, int obs, int ld, const int *__restrict__ out_rp,
+                                                       const int *__restrict__ out_ci, const double *__restrict__ out_v,
+                                                       const int *__restrict__ inT_rp, const int *__restrict__ inT_ci,
+                                                       const double *__restrict__ inT_v, const double *__restrict__ SinvO,
+                                                       double *__restrict__ S)
+{
+    extern __shared__ double T[];  // obs doubles
+    const int r = blockIdx.x, g = r0 + r;
+    const int j0 = out_rp[g], j1 = out_rp[g + 1];
+    int cnt = 0;
+    for (int j = j0; j < j1; ++j) cnt += (out_ci[j] >= o0 && out_ci[j] < o0 + obs);
+    if (cnt == 0) return;  // row does not touch block o: nothing to subtract (uniform over the workgroup)
+    for (int m = threadIdx.x; m < obs; m += kCB) {
+        double t = 0.0;
+        for (int j = j0; j < j1; ++j) {
+            const int k = out_ci[j];
+            if (k >= o0 && k < o0 + obs) t += out_v[j] * SinvO[(size_t)(k - o0) * ld + m];
+        }
+        T[m] = t;
+    }
+    __syncthreads();
+    double *row = S + (size_t)r * ld;
+    for (int c = threadIdx.x; c < bs; c += kCB) {
+        const int gc = r0 + c;
+        double acc = 0.0;
+        for (int j = inT_rp[gc]; j < inT_rp[gc + 1]; ++j) {
+            const int m = inT_ci[j];  // source row of the entry (permuted numbering)
+            if (m >= o0 && m < o0 + obs) acc += T[m - o0] * inT_v[j];
+        }
+        row[c] -= acc;
+    }
+}
+
+// |S[i][0]| for the first pivot search
+__global__ __launch_bounds__(kCB) void bt_col0_kernel(int bs, int ld, const double *__restrict__ S, double *__restrict__ colmag)
+{
+    for (int i = blockIdx.x * kCB + threadIdx.x; i < bs; i += gridDim.x * kCB) colmag[i] = fabs(S[(size_t)i * ld]);
+}
+
+// One Gauss-Jordan step (pivot column k) of the in-place inversion with row interchanges, written
+// out of place (src -> dst) so no workgroup reads what another one writes:
+//   p = argmax_{i>=k} |src[i][k]| (lowest index on ties; magnitudes come in colcur)
+//   dst[k]   = src[p] / piv, dst[k][k] = 1/piv
+//   dst[i]   = src[s] - f * dst[k], dst[i][k] = -f/piv     with s = (i == p ? k : i), f = src[s][k]
+//   colnext[i] = |dst[i][k+1]|                              (the next step's pivot search)
+constexpr int kGjRows = 8;  // rows per workgroup
+
+__global__ __launch_bounds__(kCB) void bt_gj_kernel(int k, int bs, int ld, const double *__restrict__ src, double *__restrict__ dst,
+                                                    const double *__restrict__ colcur, double *__restrict__ colnext,
+                                                    int *__restrict__ pivots, int *__restrict__ singular)
+{
+    extern __shared__ double prow[];  // bs doubles: the scaled pivot row
+    __shared__ double smax[kCB / 64];
+    __shared__ int sidx[kCB / 64];
+    __shared__ int s_p;
+    // pivot search (every workgroup finds the same p)
+    double best = -1.0;
+    int bi = k;
+    for (int i = k + threadIdx.x; i < bs; i += kCB) {
+        const double m = colcur[i];
+        if (m > best) {  // ascending i per thread: strict > keeps the lowest index
+            best = m;
+            bi = i;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_down(best, off, 64);
+        const int oi = __shfl_down(bi, off, 64);
+        if (ob > best || (ob == best && oi < bi)) {
+            best = ob;
+            bi = oi;
+        }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        smax[w] = best;
+        sidx[w] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double b = smax[0];
+        int ix = sidx[0];
+        for (int q = 1; q < kCB / 64; ++q)
+            if (smax[q] > b || (smax[q] == b && sidx[q] < ix)) {
+                b = smax[q];
+                ix = sidx[q];
+            }
+        s_p = ix;
+        if (blockIdx.x == 0) {
+            pivots[k] = ix;
+            if (!(b > 0.0)) *singular = 1;
+        }
+    }
+    __syncthreads();
+    const int p = s_p;
+    const double piv = src[(size_t)p * ld + k];
+    const double rpiv = 1.0 / piv;
+    const double *__restrict__ sp = src + (size_t)p * ld;
+    for (int j = threadIdx.x; j < bs; j += kCB) prow[j] = (j == k) ? rpiv : sp[j] * rpiv;
+    __syncthreads();
+    const int i0 = blockIdx.x * kGjRows;
+#pragma unroll 1
+    for (int q = 0; q < kGjRows; ++q) {
+        const int i = i0 + q;
+        if (i >= bs) break;
+        double *__restrict__ d = dst + (size_t)i * ld;
+        if (i == k) {
+            for (int j = threadIdx.x; j < bs; j += kCB) d[j] = prow[j];
+            continue;  // row k is never a pivot candidate again
+        }
+        const int s = (i == p) ? k : i;
+        const double *__restrict__ sr = src + (size_t)s * ld;
+        const double f = sr[k];
+        for (int j = threadIdx.x; j < bs; j += kCB) {
+            const double nv = (j == k) ? -f * rpiv : sr[j] - f * prow[j];
+            d[j] = nv;
+            if (j == k + 1) colnext[i] = fabs(nv);
+        }
+    }
+}
+
+// out[i][j] = R[i][colmap[j]] where colmap undoes the row interchanges: (PA)^-1 = A^-1 P^-1, so the
+// columns are swapped back in reverse pivot order.  One workgroup builds colmap in LDS (sequential,
+// bs steps), then all copy.
+__global__ __launch_bounds__(kCB) void bt_colmap_kernel(int bs, const int *__restrict__ pivots, int *__restrict__ colmap)
+{
+    extern __shared__ int cm[];
+    for (int j = threadIdx.x; j < bs; j += kCB) cm[j] = j;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = bs - 1; k >= 0; --k) {
+            const int p = pivots[k];
+            const int t = cm[k];
+            cm[k] = cm[p];
+            cm[p] = t;
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < bs; j += kCB) colmap[j] = cm[j];
+}
+
+__global__ __launch_bounds__(kCB) void bt_unscramble_kernel(int bs, int ld, const double *__restrict__ R, const int *__restrict__ colmap,
+                                                            double *__restrict__ out)
+{
+    const int i = blockIdx.x;
+    const double *__restrict__ r = R + (size_t)i * ld;
+    double *__restrict__ o = out + (size_t)i * ld;
+    for (int j = threadIdx.x; j < ld; j += kCB) o[j] = (j < bs) ? r[colmap[j]] : 0.0;
+}
+
+// One step of the solve for up to two blocks (blockIdx.y).  mode 0 (inward):
+//   w = b[perm] - Aout z ; z_blk = Sinv w.       mode 1 (outward): w = Ain z ; z_blk -= Sinv w.
+// When `final_` the block's rows of the solution are also scattered to x (original numbering).
+// Each workgroup owns kSolveRows rows of the block's GEMV (a wave takes two rows at a time) and first
+// builds the whole w in LDS (sparse, few entries per row).
+constexpr int kSolveRows = 8;
+
+struct BtStep {
+    int r0[2], bs[2], blk[2];
+    int nblk;
+};
+
+__global__ __launch_bounds__(kCB) void bt_solve_kernel(BtStep s, int mode, int final_, int ld, size_t blk_stride,
+                                                       const double *__restrict__ sinv, const int *__restrict__ perm,
+                                                       const int *__restrict__ a_rp, const int *__restrict__ a_ci,
+                                                       const double *__restrict__ a_v, const double *__restrict__ b,
+                                                       double *__restrict__ z, double *__restrict__ x)
+{
+    extern __shared__ double w[];
+    const int which = blockIdx.y;
+    const int r0 = s.r0[which], bs = s.bs[which];
+    const int row0 = blockIdx.x * kSolveRows;
+    if (row0 >= bs) return;  // the second block of a step may be the shorter last block
+    for (int r = threadIdx.x; r < bs; r += kCB) {
+        const int g = r0 + r;
+        double acc = 0.0;
+        for (int j = a_rp[g]; j < a_rp[g + 1]; ++j) acc += a_v[j] * z[a_ci[j]];
+        w[r] = mode == 0 ? b[perm[g]] - acc : acc;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const double *__restrict__ M = sinv + (size_t)s.blk[which] * blk_stride;
+    const int ra = row0 + 2 * wv, rb = ra + 1;
+    if (ra >= bs) return;
+    const bool hb = rb < bs;
+    const double *__restrict__ ma = M + (size_t)ra * ld;
+    const double *__restrict__ mb = M + (size_t)(hb ? rb : ra) * ld;
+    double sa = 0.0, sb = 0.0;
+    // ld is a multiple of 64 and rows are padded with zeros, so the 16-byte loads stay aligned / in bounds
+    for (int j = lane * 2; j < bs; j += 128) {
+        const double2 va = *reinterpret_cast<const double2 *>(ma + j);
+        const double2 vb = *reinterpret_cast<const double2 *>(mb + j);
+        const double w0 = w[j], w1 = (j + 1 < bs) ? w[j + 1] : 0.0;
+        sa += va.x * w0;
+        sa += va.y * w1;
+        sb += vb.x * w0;
+        sb += vb.y * w1;
+    }
+    sa = wsum(sa);
+    sb = wsum(sb);
+    if (lane == 0) {
+        const int ga = r0 + ra;
+        const double za = mode == 0 ? sa : z[ga] - sa;
+        z[ga] = za;
+        if (final_) x[perm[ga]] = za;
+        if (hb) {
+            const int gb = r0 + rb;
+            const double zb = mode == 0 ? sb : z[gb] - sb;
+            z[gb] = zb;
+            if (final_) x[perm[gb]] = zb;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kCB) void cvt_f2d_kernel(int n, const float *__restrict__ in, double *__restrict__ out)
+{
+    for (int i = blockIdx.x * kCB + threadIdx.x; i < n; i += gridDim.x * kCB) out[i] = (double)in[i];
+}
+
+}  // namespace
+
+void bt_launch_diag(int r0, int bs, int ld, const int *rp, const int *ci, const double *v, double *S, hipStream_t st)
+{
+    hipLaunchKernelGGL(bt_diag_kernel, dim3(bs), dim3(kCB), 0, st, r0, bs, ld, rp, ci, v, S);
+}
+
+void bt_launch_schur(int r0, int bs, int o0, int obs, int ld, const BtDevCsr &out, const BtDevCsr &inT, const double *SinvO, double *S,
+                     hipStream_t st)
+{
+    hipLaunchKernelGGL(bt_schur_kernel, dim3(bs), dim3(kCB), (size_t)obs * sizeof(double), st, r0, bs, o0, obs, ld, out.rp, out.ci, out.v,
+                       inT.rp, inT.ci, inT.v, SinvO, S);
+}
+
+// inverts S (bs x bs, ld) into out; S and S2 are scratch.  Enqueues bs + 3 launches.
+void bt_launch_invert(int bs, int ld, double *S, double *S2, double *col0, double *col1, int *pivots, int *colmap, int *singular,
+                      double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(bt_col0_kernel, dim3((bs + kCB - 1) / kCB), dim3(kCB), 0, st, bs, ld, S, col0);
+    const int grid = (bs + kGjRows - 1) / kGjRows;
+    double *src = S, *dst = S2, *cc = col0, *cn = col1;
+    for (int k = 0; k < bs; ++k) {
+        hipLaunchKernelGGL(bt_gj_kernel, dim3(grid), dim3(kCB), (size_t)bs * sizeof(double), st, k, bs, ld, src, dst, cc, cn, pivots, singular);
+        double *t = src;
+        src = dst;
+        dst = t;
+        t = cc;
+        cc = cn;
+        cn = t;
+    }
+    hipLaunchKernelGGL(bt_colmap_kernel, dim3(1), dim3(kCB), (size_t)bs * sizeof(int), st, bs, pivots, colmap);
+    hipLaunchKernelGGL(bt_unscramble_kernel, dim3(bs), dim3(kCB), 0, st, bs, ld, src, colmap, out);
+}
+
+void bt_launch_solve_step(const int r0[2], const int bs[2], const int blk[2], int nblk, int mode, int final_, int ld, size_t blk_stride,
+                          const double *sinv, const int *perm, const BtDevCsr &A, const double *b, double *z, double *x, hipStream_t st)
+{
+    BtStep s;
+    int mx = 0;
+    for (int q = 0; q < 2; ++q) {
+        s.r0[q] = r0[q < nblk ? q : 0];
+        s.bs[q] = bs[q < nblk ? q : 0];
+        s.blk[q] = blk[q < nblk ? q : 0];
+        if (q < nblk) mx = bs[q] > mx ? bs[q] : mx;
+    }
+    s.nblk = nblk;
+    const int gx = (mx + kSolveRows - 1) / kSolveRows;
+    hipLaunchKernelGGL(bt_solve_kernel, dim3(gx, nblk), dim3(kCB), (size_t)mx * sizeof(double), st, s, mode, final_, ld, blk_stride, sinv, perm,
+                       A.rp, A.ci, A.v, b, z, x);
+}
+
+void launch_cvt_f2d(int n, const float *in, double *out, hipStream_t st)
+{
+    if (n <= 0) return;
+    int g = (n + kCB * 2 - 1) / (kCB * 2);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(cvt_f2d_kernel, dim3(g), dim3(kCB), 0, st, n, in, out);
+}
+
+}  // namespace sparsh

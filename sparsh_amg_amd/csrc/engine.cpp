@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <omp.h>
 
 namespace sparsh {
 
@@ -388,6 +389,7 @@ int Engine::setup_host(const sparsh_params &p)
     sp.limit_lower = p.limit_lower;
     sp.coarsening = p.coarsening;
     sp.coarse_limit = p.coarse_limit;
+    if (p.dense_limit > 0) sp.dense_limit = p.dense_limit;
     sp.host_threads = p.host_threads;
     sp.print = p.print_setup != 0;
     if (!build_hierarchy(A0_, sp, H_)) {
@@ -434,6 +436,7 @@ int Engine::setup(const sparsh_params &p)
     if (!st_ && !check(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking), "hipStreamCreate")) return SPARSH_ENODEV;
     for (void *q : allocs_) (void)hipFree(q);  // a second setup replaces the resident hierarchy
     allocs_.clear();
+    coarse_.release();
     if (!comm_) comm_ = make_self_comm();
     const int G = comm_->size, me = comm_->rank;
 
@@ -527,9 +530,20 @@ int Engine::setup(const sparsh_params &p)
         (void)hipMemsetAsync(d.r, 0, rcap * 8, st_);
     }
     nL_ = H_.nL;
-    coarse_inv_ = upload(*this, H_.coarse_inverse.data(), (size_t)nL_ * nL_);
-    if (!coarse_inv_) return SPARSH_ENODEV;
-    std::vector<double>().swap(H_.coarse_inverse);  // host copy no longer needed
+    if (H_.coarse_dense) {
+        if (!coarse_.setup_dense(nL_, H_.coarse_inverse.data(), error)) return SPARSH_ENODEV;
+        std::vector<double>().swap(H_.coarse_inverse);  // host copy no longer needed
+    } else {
+        // large coarsest level (the reference's level1 = 6 policy at >= ~260 k rows): block-tridiagonal
+        // factorisation on the device
+        const double t_f = omp_get_wtime();
+        int why = 0;
+        if (!coarse_.setup_bt(H_.levels.back().A, st_, error, &why)) return why == 1 ? SPARSH_EINVAL : (why == 2 ? SPARSH_ENUMERIC : SPARSH_ENODEV);
+        setup_seconds += omp_get_wtime() - t_f;
+        if (p.print_setup && (G == 1 || me == 0))
+            std::printf("coarsest level: %d rows, RCM bandwidth %d -> %d blocks of %d, factors %.1f MB in HBM, %.2f s\n", nL_, coarse_.bandwidth(),
+                        coarse_.nblocks(), coarse_.block(), coarse_.bytes() / 1e6, coarse_.factor_seconds);
+    }
 
     part_cap_ = max_blk + 8;
     part0_ = static_cast<double *>(dalloc((size_t)part_cap_ * 8));
@@ -613,9 +627,15 @@ bool Engine::setup_f32()
             }
         }
     }
-    coarse_inv_f32_ = static_cast<float *>(dalloc((size_t)nL_ * nL_ * 4));
-    if (!coarse_inv_f32_) return false;
-    launch_cvt_d2f((long)nL_ * nL_, coarse_inv_, coarse_inv_f32_, st_);
+    if (coarse_.dense()) {
+        coarse_inv_f32_ = static_cast<float *>(dalloc((size_t)nL_ * nL_ * 4));
+        if (!coarse_inv_f32_) return false;
+        launch_cvt_d2f((long)nL_ * nL_, coarse_.dense_inverse(), coarse_inv_f32_, st_);
+    } else {  // block-tridiagonal factors stay fp64: b_L and x_L are converted around the solve
+        coarse_inv_f32_ = nullptr;
+        coarse_tmp_ = static_cast<double *>(dalloc((size_t)nL_ * 2 * 8));
+        if (!coarse_tmp_) return false;
+    }
     f32_ready_ = true;
     return true;
 }
@@ -647,7 +667,13 @@ void Engine::vcycle_f32(const double *r64, double *z64, double *partial, int *nb
         apply(l, OP_RESID, f.x, f.r);
         launch_restrict_f32(lev_[l + 1].n, lev_[l].R.rowptr, lev_[l].R.col, lev_[l].R.val, f.r, f32_[l + 1].b, st_);
     }
-    launch_gemv_f32(nL_, coarse_inv_f32_, f32_[last].b, f32_[last].x, st_);
+    if (coarse_inv_f32_) {
+        launch_gemv_f32(nL_, coarse_inv_f32_, f32_[last].b, f32_[last].x, st_);
+    } else {
+        launch_cvt_f2d(nL_, f32_[last].b, coarse_tmp_, st_);
+        coarse_.solve(coarse_tmp_, coarse_tmp_ + nL_, st_);
+        launch_cvt_d2f(nL_, coarse_tmp_ + nL_, f32_[last].x, st_);
+    }
     for (int l = last; l > 0; --l) {
         DevLevel &F = lev_[l - 1];
         if (F.P_is_aggregation)
@@ -815,7 +841,7 @@ void Engine::op_prolong(int l, const double *xc, double *xf)
     }
 }
 
-void Engine::op_coarse(const double *b, double *x) { launch_gemv(nL_, coarse_inv_, b, x, st_); }
+void Engine::op_coarse(const double *b, double *x) { coarse_.solve(b, x, st_); }
 
 double Engine::op_dot(int n, const double *x, const double *y)
 {

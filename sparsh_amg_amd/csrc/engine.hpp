@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/sparsh_amg.h"
+#include "coarse.hpp"
 #include "comm.hpp"
 #include "dist.hpp"
 #include "host_setup.hpp"
@@ -69,6 +70,7 @@ public:
     bool host_ready() const { return host_ready_; }
     int nlevels() const { return (int)lev_.size(); }
     const HostHierarchy &host() const { return H_; }
+    const CoarseSolver &coarse() const { return coarse_; }
     const sparsh_params &params() const { return prm_; }
     // average seconds of one communication step alone (collective: every rank calls it): what = 0 halo
     // exchange of level `level`'s operator, 1 the 16-byte all-reduce of the fused scalars, 2 the
@@ -166,7 +168,8 @@ private:
     HostHierarchy H_;
     sparsh_params prm_{};
     std::vector<DevLevel> lev_;
-    double *coarse_inv_ = nullptr;
+    CoarseSolver coarse_;  // coarsest-level direct solver (dense inverse or block-tridiagonal factors)
+    double *coarse_tmp_ = nullptr;  // fp32 mode with the block-tridiagonal form: fp64 staging of b_L, x_L
     int nL_ = 0;
     hipStream_t st_ = nullptr;
     bool ready_ = false;

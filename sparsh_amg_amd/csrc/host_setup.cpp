@@ -510,6 +510,8 @@ void band_solve_unit(const BandLU &F, int c, int kstart, double *y)
 
 }  // namespace
 
+std::vector<int> rcm_order(const HostCsr &A) { return rcm(A); }
+
 bool sparse_inverse(const HostCsr &A, std::vector<double> &inv)
 {
     const int n = A.nrow;
@@ -554,9 +556,11 @@ bool build_hierarchy(const HostCsr &A0, const SetupParams &prm, HostHierarchy &H
     for (;;) {
         const int n = H.levels[l].A.nrow;
         const bool within_ref = l < prm.max_levels - 1;
-        // reference rule: coarsen while n > limit_upper and fewer than max_levels levels exist.
-        // Deviation: if that leaves a coarsest level above coarse_limit (the device applies a dense
-        // inverse), keep coarsening by the same rule until n <= limit_upper.
+        // reference rule: coarsen while n > limit_upper and fewer than max_levels levels exist
+        // (src/AMG_phases.cpp:51,77); whatever is left goes to the direct solver (:89).  That is
+        // followed up to coarse_limit rows (dense inverse up to dense_limit, block-tridiagonal
+        // factorisation above).  Opt-out for very large problems: if max_levels would leave more than
+        // coarse_limit rows, keep coarsening by the same rule until n <= limit_upper.
         if (!within_ref && n > prm.coarse_limit) H.extended = true;
         if (!(n > prm.limit_upper && (within_ref || H.extended))) break;
         if (prm.print) std::printf("Level %d:\t%d\n", l, n);
@@ -590,13 +594,13 @@ bool build_hierarchy(const HostCsr &A0, const SetupParams &prm, HostHierarchy &H
     if (prm.print) std::printf("Level %d:\t%d\n", l, H.levels[l].A.nrow);
     const HostCsr &AL = H.levels[l].A;
     H.nL = AL.nrow;
-    if (H.nL > std::max(prm.coarse_limit, prm.limit_upper) * 2) {
-        H.error = "coarsest level has " + std::to_string(H.nL) + " rows: too large for the device direct solve (coarsening stalled)";
-        return false;
-    }
     if (H.extended && prm.print)
         std::printf("note: hierarchy extended past %d levels (coarsest level would exceed coarse_limit=%d)\n", prm.max_levels, prm.coarse_limit);
-    if (!sparse_inverse(AL, H.coarse_inverse)) {
+    // small coarsest level: explicit inverse now; a larger one is factored on the device
+    // (block-tridiagonal form, coarse.cpp) when the hierarchy is uploaded
+    H.coarse_dense = H.nL <= prm.dense_limit;
+    H.coarse_inverse.clear();
+    if (H.coarse_dense && !sparse_inverse(AL, H.coarse_inverse)) {
         H.error = "coarsest-level matrix is singular";
         return false;
     }

@@ -49,7 +49,8 @@ struct SetupParams {
     int limit_upper = 4000;
     int limit_lower = 2000;
     int coarsening = 0;  // 0 HEM, 1 Beck
-    int coarse_limit = 8192;
+    int coarse_limit = 40000;  // largest coarsest level max_levels may leave (above: keep coarsening)
+    int dense_limit = 8192;    // largest coarsest level solved with an explicit dense inverse
     int host_threads = 0;
     bool print = true;
 };
@@ -64,8 +65,10 @@ struct HostLevel {
 
 struct HostHierarchy {
     std::vector<HostLevel> levels;
-    // coarsest level: explicit inverse, row-major nL x nL
+    // coarsest level: explicit inverse, row-major nL x nL, when nL <= dense_limit (coarse_dense);
+    // otherwise the device factors it (coarse.cpp) and coarse_inverse stays empty
     int nL = 0;
+    bool coarse_dense = true;
     std::vector<double> coarse_inverse;
     double seconds = 0.0;
     bool extended = false;  // hierarchy continued past max_levels because of coarse_limit
@@ -80,6 +83,8 @@ HostCsr beck_prolongator(const HostCsr &A);
 HostCsr transpose(const HostCsr &A);
 HostCsr galerkin(const HostCsr &A, const HostCsr &P, const HostCsr &R, bool P_is_aggregation);
 std::vector<double> extract_diagonal(const HostCsr &A);
+// reverse Cuthill-McKee ordering of the symmetrised pattern: order[new] = old
+std::vector<int> rcm_order(const HostCsr &A);
 // dense inverse of a sparse matrix through RCM + banded LU (partial pivoting); false if singular
 bool sparse_inverse(const HostCsr &A, std::vector<double> &inv);
 

@@ -1,0 +1,152 @@
+"""Device coarse direct solver for LARGE coarsest levels (csrc/coarse.cpp, coarse_kernels.hip) and the
+reference's own level policy on the device.  GPU box only.
+
+The reference stops coarsening after level1 = 6 levels and hands whatever is left to PARDISO
+(/root/reference/src/AMG_phases.cpp:51,77,89; src/AMG_coarse_level_solver.cpp:64-76): 31 250 rows at
+100^3.  The device solves such a level with a block-tridiagonal factorisation of the RCM-ordered
+operator (explicit inverses of the Schur-complement diagonal blocks, factored and applied on the
+GPU).  Checked here: the solver against scipy's sparse LU, and the only >= 1 M-row vector captured
+from the reference (SURVEY Appendix A.2, 100^3: 6 levels, 21 PCG iterations, 65 AMG cycles) on the
+HIP path to the SURVEY §8d tolerance.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+import oracle
+import sparsh_amg_amd as sa
+from sparsh_amg_amd import problems
+from conftest import hist_tolerance
+
+pytestmark = pytest.mark.gpu
+
+QUIET = dict(print_setup=0, print_solve=0)
+ONE_LEVEL = dict(max_levels=1, coarse_limit=1 << 30, limit_upper=1 << 30)  # the whole matrix is the "coarsest level"
+
+
+def _nonsym3d(m):
+    """7-pt grid operator with direction-dependent coefficients (nonsymmetric: PARDISO mtype 11 is general)."""
+    rp, ci, v = problems.poisson3d(m)
+    rows = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
+    v = v.copy()
+    v[ci > rows] *= 1.07
+    v[ci == rows] += 0.01 * (rows % 5)
+    return rp, ci, v
+
+
+@pytest.mark.parametrize("name,gen", [
+    ("p3d_24", lambda: problems.poisson3d(24)),          # 13 824 rows, bandwidth ~ 24^2
+    ("p2d_150", lambda: problems.poisson2d(150)),        # 22 500 rows, narrow band -> blocks padded to 1024 wide
+    ("nonsym3d_22", lambda: _nonsym3d(22)),              # pivoting inside the diagonal blocks
+    ("p3d_ragged_last_block", lambda: problems.poisson3d(21)),  # 9261 rows: short last block
+])
+def test_block_tridiagonal_solver_vs_sparse_lu(name, gen):
+    rp, ci, v = gen()
+    n = len(rp) - 1
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET, **ONE_LEVEL, dense_limit=2000))
+    try:
+        info = A.coarse_info()
+        assert A.nlevels == 1 and info["rows"] == n and not info["dense"]
+        assert info["nblocks"] >= 2 and info["block"] % 64 == 0 and info["block"] >= info["bandwidth"]
+        S = sp.csr_matrix((v, ci, rp), shape=(n, n))
+        lu = spla.splu(S.tocsc())
+        rng = np.random.default_rng(1)
+        for b in (np.ones(n), rng.standard_normal(n)):
+            x = A.op_coarse(b)
+            xr = lu.solve(b)
+            assert np.linalg.norm(x - xr) <= 1e-11 * np.linalg.norm(xr), name
+            assert np.linalg.norm(b - S @ x) <= 1e-11 * np.linalg.norm(b)
+        # deterministic: no atomics anywhere in the factorisation or the solve
+        assert np.array_equal(A.op_coarse(np.ones(n)), A.op_coarse(np.ones(n)))
+    finally:
+        A.close()
+
+
+def test_dense_and_block_form_agree():
+    """Same hierarchy, coarsest level once through the dense inverse, once through the block factors."""
+    rp, ci, v = problems.poisson3d(40)
+    b = np.ones(len(rp) - 1)
+    hs, xs = [], []
+    for dl in (8192, 1000):
+        A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET, dense_limit=dl))
+        assert A.coarse_info()["dense"] == (dl == 8192) and A.level_info(A.nlevels - 1)["nrow"] == 4000
+        x = np.zeros_like(b)
+        h, rc = A.solve("pcg", b, x)
+        assert rc == 0
+        hs.append(h)
+        xs.append(x)
+        A.close()
+    assert len(hs[0]) == len(hs[1])
+    assert np.all(np.abs(hs[0] - hs[1]) <= hist_tolerance(hs[0]) * hs[0])
+    assert np.linalg.norm(xs[0] - xs[1]) <= 1e-9 * np.linalg.norm(xs[0])
+
+
+def test_too_wide_operator_is_refused():
+    """A random sparsity pattern has no band structure: the block form would need blocks beyond the
+    limit, and the setup must say so instead of building something huge."""
+    rp, ci, v = problems.random_spd(20000, 9, seed=5)
+    A = sa.sp_matrix_mg(rp, ci, v)
+    with pytest.raises(sa.SparshError) as e:
+        A.setup(sa.default_params(**QUIET, **ONE_LEVEL))
+    assert "too wide" in str(e.value)
+
+
+def _hist_ok(h, ref):
+    h, ref = np.asarray(h), np.asarray(ref)
+    assert len(h) == len(ref), (len(h), len(ref))
+    err = np.abs(h - ref) / ref
+    assert np.all(err <= hist_tolerance(ref)), f"max rel err {err.max():.3e} at {err.argmax()}"
+
+
+@pytest.fixture(scope="module")
+def p100():
+    rp, ci, v = problems.poisson3d(100)
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET))  # defaults: max_levels = 6 honoured
+    yield A
+    A.close()
+
+
+def test_reference_level_policy_100cubed(p100, golden):
+    A = p100
+    g = golden["poisson3d_100"]["hem"]
+    assert [A.level_info(l)["nrow"] for l in range(A.nlevels)] == g["levels_nrow"]       # 6 levels, 31 250-row coarsest
+    assert [A.level_info(l)["nnz"] for l in range(A.nlevels)] == g["levels_nnz_stored"]
+    info = A.coarse_info()
+    assert info["rows"] == 31250 and not info["dense"] and not info["extended"]
+
+
+def test_golden_100cubed_pcg_on_device(p100, golden):
+    """Appendix A.2: Solver_PCG_1 on 7-pt 100^3 -- 21 iterations, residuals of the reference's own CPU run."""
+    A = p100
+    g = golden["poisson3d_100"]["hem"]["pcg"]
+    b = np.ones(A.nrow)
+    x = np.zeros(A.nrow)
+    h, rc = A.solve("pcg", b, x)
+    assert rc == 0 and len(h) == g["iterations"] == 21
+    _hist_ok(h, g["hist"])
+    assert abs(h[0] - g["hist"][0]) <= 1e-10 * g["hist"][0]
+    assert abs(np.linalg.norm(x) - g["xnorm"]) <= 1e-9 * g["xnorm"]
+    assert abs(x[0] - g["x0"]) <= 1e-8
+
+
+def test_golden_100cubed_amg_on_device(p100, golden):
+    """Appendix A.2: AMG_Solver_CPU_baseline on 100^3 -- 65 V(7,7) cycles; last two residuals captured."""
+    A = p100
+    g = golden["poisson3d_100"]["hem"]["amg"]
+    x = np.zeros(A.nrow)
+    h, rc = A.solve("amg", np.ones(A.nrow), x)
+    assert rc == 0 and len(h) == g["cycles"] == 65
+    assert np.allclose(h[-2:], g["hist_tail"], rtol=1e-3)
+
+
+def test_fp32_preconditioner_with_block_coarse_solver():
+    """The opt-in float V-cycle keeps the block factors in fp64 and converts b_L / x_L around the solve."""
+    rp, ci, v = problems.poisson3d(40)
+    b = np.ones(len(rp) - 1)
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET, dense_limit=1000, precond_fp32=1))
+    x = np.zeros_like(b)
+    h, rc = A.solve("pcg", b, x)
+    S = sp.csr_matrix((v, ci, rp))
+    assert rc == 0 and np.linalg.norm(b - S @ x) <= 1.0001e-8
+    A.close()

@@ -152,3 +152,36 @@ def test_product_does_not_touch_oracle():
                 if re.search(r"amg_oracle|import oracle|from oracle|oracle/", txt):
                     bad.append(f)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("args", [("12", "3", "8"), ("40", "2", "8"), ("9", "3", "3"), ("30", "2", "2"), ("70", "2", "64")])
+def test_block_tridiagonal_plan_on_host(tmp_path_factory, args):
+    """csrc/coarse.cpp bt_make_plan (RCM blocks, diag/out/in pieces, inward/outward schedule) driven through a
+    dense host emulation of the device kernels' algebra: the twisted block factorisation must solve A x = b."""
+    import subprocess
+
+    d = tmp_path_factory.getbasetemp() / "btplan"
+    d.mkdir(exist_ok=True)
+    exe = d / "bt_plan_check"
+    if not exe.exists():
+        lib_dir = os.path.join(ROOT, "sparsh_amg_amd")
+        cmd = ["g++", "-std=c++17", "-O2", "-D__HIP_PLATFORM_AMD__", f"-I{os.path.join(lib_dir, 'csrc')}", "-I/opt/rocm/include",
+               os.path.join(ROOT, "tests", "cpp", "bt_plan_check.cpp"), "-o", str(exe), f"-L{lib_dir}", "-lsparsh_amg",
+               f"-Wl,-rpath,{lib_dir}", "-L/opt/rocm/lib", "-L/opt/rocm/lib/llvm/lib", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib/llvm/lib"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe), *args], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-500:])
+    assert "relerr" in r.stdout
+
+
+def test_reference_level_policy_is_the_default():
+    """Up to coarse_limit (40 000) rows left over, max_levels = 6 is honoured exactly as the reference does
+    (src/AMG_phases.cpp:51,77): 100^3 -> 6 levels with a 31 250-row coarsest level for the direct solver."""
+    rp, ci, v = problems.poisson3d(100)
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0), host_only=True)
+    assert [A.level_info(l)["nrow"] for l in range(A.nlevels)] == [1000000, 500000, 250000, 125000, 62500, 31250]
+    info = A.coarse_info()
+    assert info["rows"] == 31250 and not info["dense"] and not info["extended"]
+    with pytest.raises(sa.SparshError):
+        A.coarse_inverse()  # no dense inverse above dense_limit
