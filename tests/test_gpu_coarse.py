@@ -31,7 +31,8 @@ def _nonsym3d(m):
     rows = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
     v = v.copy()
     v[ci > rows] *= 1.07
-    v[ci == rows] += 0.01 * (rows % 5)
+    d = ci == rows
+    v[d] += 0.01 * (rows[d] % 5)
     return rp, ci, v
 
 
