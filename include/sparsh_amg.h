@@ -24,11 +24,11 @@ extern "C" {
 
 #define SPARSH_OK 0
 #define SPARSH_EINVAL -1    /* bad argument */
-#define SPARSH_ENODEV -2    /* no HIP device / HIP runtime error */
+#define SPARSH_ENODEV -2    /* no HIP device / HIP runtime error (on the solve path: sticky until the next sparsh_setup) */
 #define SPARSH_ESTATE -3    /* call order violated (e.g. solve before setup) */
 #define SPARSH_ENUMERIC -4  /* singular coarse matrix, NaN residual */
 #define SPARSH_ENOCONV -5   /* iteration cap reached before ||r|| <= tol (x still returned) */
-#define SPARSH_ECOMM -6     /* RCCL failure */
+#define SPARSH_ECOMM -6     /* transport (RCCL) failure on the solve path; sticky until the next sparsh_setup */
 
 /* Solver selection: which reference entry point's arithmetic is followed. */
 #define SPARSH_AMG 0    /* AMG_Solver_CPU_baseline / _CPU_GPU_MI / _CPU_GPU_CI  (src/AMG_main_solvers.cpp:14-26,240-268) */
@@ -103,14 +103,14 @@ int sparsh_setup(sparsh_handle h, const sparsh_params *p);
  * cap; how often the residual norm is read back).  max_iter/check_every <= 0 keep their value. */
 int sparsh_set_stopping(sparsh_handle h, double tol, int max_iter, int check_every);
 
-/* Process-wide choice of the SpMV-type kernel family (A/B measurements; all families produce
- * bitwise identical results).  kind: 0 workgroup CSR-stream, 1 wave CSR-stream, 2 sliced-ELL mirror,
+/* Per-handle choice of the SpMV-type kernel family (A/B measurements; all families produce
+ * bitwise identical results; nothing here is process-wide state).  kind: 0 workgroup CSR-stream, 1 wave CSR-stream, 2 sliced-ELL mirror,
  * 3 sliced-diagonal mirror (default); 2 and 3 fall back (3 -> 2 -> 0) where the operator does not
  * qualify for the mirror; vec: paired 16-B/8-B loads in
  * the stream phase; nt: non-temporal loads for the matrix stream; remap: 0 none, 1 each XCD owns a
  * contiguous eighth of the row blocks, G > 1 groups of G row blocks dealt round-robin to the XCDs.
  * nt < 0 or remap < 0 selects the built-in per-operator policy (default). */
-int sparsh_set_kernel_config(int kind, int vec, int nt, int remap);
+int sparsh_set_kernel_config(sparsh_handle h, int kind, int vec, int nt, int remap);
 
 /* Which layout the SpMV-type kernels of a level use under the current config (3 sliced diagonals,
  * 2 sliced ELL, 1 wave CSR-stream, 0 workgroup CSR-stream) and how many entries it stores
@@ -126,10 +126,10 @@ int sparsh_level_format(sparsh_handle h, int level, int *kind, long *stored_entr
  * (nearly) all of them draw their (offset, constant) pairs from one set of at most 8, that set
  * travels as a kernel argument and a slice only needs its 8 lane masks (64 B).
  * meta_bytes = bytes of slice/slot descriptors one sweep reads.  All 0 when the level does not use
- * the layout.  sparsh_set_const_slots(0) before sparsh_setup turns the folding off (A/B
- * measurements; default on). */
+ * the layout.  sparsh_set_const_slots(h, 0) before sparsh_setup(h, ...) turns the folding off for that
+ * handle (A/B measurements; default on). */
 int sparsh_level_layout(sparsh_handle h, int level, long *slots, long *value_blocks, long *meta_bytes);
-int sparsh_set_const_slots(int enable);
+int sparsh_set_const_slots(sparsh_handle h, int enable);
 /* Multi-GPU diagnostics (collective: every rank calls it with the same arguments): average seconds
  * of one communication step alone, timed with HIP events on the engine's stream.  what = 0: halo
  * exchange of level `level`'s operator; 1: the 16-byte all-reduce of the fused scalars; 2: the
@@ -139,6 +139,9 @@ int sparsh_bench_comm(sparsh_handle h, int what, int level, int reps, double *av
 /* name of the kernel the SpMV-type operations of a level launch under the current config
  * ("sdia_tab_kernel", "sdia_kernel", "sell_kernel", "csr_wave_kernel", "csr_block_kernel") */
 const char *sparsh_level_kernel(sparsh_handle h, int level);
+/* placement the launcher uses for that level's operator under the handle's config: nt = 1 when the
+ * matrix stream is read with non-temporal loads, remap = XCD mapping mode (see sparsh_set_kernel_config) */
+int sparsh_level_placement(sparsh_handle h, int level, int *nt, int *remap);
 
 /* Host half of sparsh_setup only (coarsening, Galerkin products, coarse factorisation); needs
  * no GPU.  Enables the inspection calls below; solvers still require sparsh_setup. */
@@ -250,6 +253,10 @@ int sparsh_set_overlap(sparsh_handle h, int enable);
 int sparsh_comm_group_create(int nranks, void **group);
 void sparsh_comm_group_destroy(void *group);
 int sparsh_comm_init_group(sparsh_handle h, void *group, int rank);
+/* fault injection for tests: from its ncalls-th halo exchange on (counted per rank, 0-based) the in-process
+ * transport fails on every rank.  Solvers must then return SPARSH_ECOMM, and the handle keeps
+ * returning it (sticky) until sparsh_setup is called again.  ncalls < 0 switches the hook off. */
+int sparsh_comm_group_fail_after(void *group, int ncalls);
 
 /* Host-only planning query (after sparsh_setup_host): the block of operator `which` (0 A_l, 1 P_l,
  * 2 R_l) that `rank` of `nranks` holds when every level is partitioned, with its halo plan.

@@ -111,6 +111,10 @@ def lib():
         fn = getattr(L, name)
         fn.restype = C.c_int
         fn.argtypes = [P(OCsr), c_dbl_p, c_dbl_p, P(OParams), c_dbl_p, C.c_int]
+    L.oracle_time_spmv.restype = C.c_double
+    L.oracle_time_spmv.argtypes = [P(OCsr), c_dbl_p, c_dbl_p, C.c_int, C.c_int]
+    L.oracle_stream_triad.restype = C.c_double
+    L.oracle_stream_triad.argtypes = [C.c_long, C.c_int, C.c_int]
     L.oracle_pcg_presetup.restype = C.c_int
     L.oracle_pcg_presetup.argtypes = [C.c_void_p, c_dbl_p, c_dbl_p, C.c_int, c_dbl_p, C.c_int, c_dbl_p]
     _lib = L
@@ -206,6 +210,18 @@ def spmv(A: Csr, x):
     y = np.empty(A.shape[0])
     lib().oracle_spmv(A.ptr, _dp(x), _dp(y))
     return y
+
+
+def time_spmv(A: Csr, reps=10, threads=0):
+    """Average seconds of one CPU y = A x (cpu_baseline leg of bench.py)."""
+    x = np.ones(A.shape[1])
+    y = np.empty(A.shape[0])
+    return lib().oracle_time_spmv(A.ptr, _dp(x), _dp(y), reps, threads)
+
+
+def stream_triad(n=1 << 26, reps=5, threads=0):
+    """Host STREAM-triad rate in GB/s (cpu_baseline leg of bench.py)."""
+    return lib().oracle_stream_triad(n, reps, threads)
 
 
 def spmv_t(A: Csr, x):

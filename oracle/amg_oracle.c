@@ -228,6 +228,51 @@ void oracle_spmv(const ocsr *A, const double *x, double *y)
     }
 }
 
+double oracle_time_spmv(const ocsr *A, const double *x, double *y, int reps, int threads)
+{
+    oracle_set_threads(threads);
+    oracle_spmv(A, x, y);
+    const double t0 = now_sec();
+    for (int r = 0; r < reps; r++) oracle_spmv(A, x, y);
+    return (now_sec() - t0) / (reps > 0 ? reps : 1);
+}
+
+double oracle_stream_triad(long n, int reps, int threads)
+{
+    oracle_set_threads(threads);
+    double *a = (double *)malloc(sizeof(double) * (size_t)n);
+    double *b = (double *)malloc(sizeof(double) * (size_t)n);
+    double *c = (double *)malloc(sizeof(double) * (size_t)n);
+    if (!a || !b || !c) {
+        free(a);
+        free(b);
+        free(c);
+        return 0.0;
+    }
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; i++) {
+        a[i] = 0.0;
+        b[i] = 1.0;
+        c[i] = 2.0;
+    }
+    double best = 0.0;
+    for (int r = 0; r < reps; r++) {
+        const double s = 3.0 + r;
+        const double t0 = now_sec();
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < n; i++) a[i] = b[i] + s * c[i];
+        const double dt = now_sec() - t0;
+        const double gbs = 24.0 * (double)n / dt / 1e9;
+        if (gbs > best) best = gbs;
+    }
+    volatile double sink = a[n / 2];
+    (void)sink;
+    free(a);
+    free(b);
+    free(c);
+    return best;
+}
+
 /* mkl_sparse_d_mv(TRANSPOSE, 1.0, A, x, 0.0, y): y = A^T x, sequential scatter */
 void oracle_spmv_t(const ocsr *A, const double *x, double *y)
 {

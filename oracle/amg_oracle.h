@@ -97,6 +97,14 @@ int oracle_solver_pbicg(ocsr *A, const double *b, double *x, const oparams *prm,
  * at most max_it iterations). Returns iterations done; *seconds = solve-loop time. */
 int oracle_pcg_presetup(oamg *S, const double *b, double *x, int max_it, double *hist, int hist_cap, double *seconds);
 
+/* ---- cpu_baseline helpers of bench.py (timing only) ----
+ * oracle_time_spmv: average seconds of one y = A x (the reference's mkl_sparse_d_mv call,
+ * src/AMG_cycle_utilities.cpp:87) over `reps` repetitions after one warm-up, `threads` OpenMP threads.
+ * oracle_stream_triad: best GB/s of a[i] = b[i] + s*c[i] over n doubles (24 n bytes per pass,
+ * first-touch initialised by the same static schedule), `reps` passes: the host's STREAM-triad rate. */
+double oracle_time_spmv(const ocsr *A, const double *x, double *y, int reps, int threads);
+double oracle_stream_triad(long n, int reps, int threads);
+
 #ifdef __cplusplus
 }
 #endif

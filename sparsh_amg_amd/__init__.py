@@ -81,10 +81,11 @@ def _load():
         "sparsh_setup": (C.c_int, [H, P(Params)]),
         "sparsh_setup_host": (C.c_int, [H, P(Params)]),
         "sparsh_set_stopping": (C.c_int, [H, C.c_double, C.c_int, C.c_int]),
-        "sparsh_set_kernel_config": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+        "sparsh_set_kernel_config": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "sparsh_level_placement": (C.c_int, [H, C.c_int, c_int_p, c_int_p]),
         "sparsh_level_format": (C.c_int, [H, C.c_int, c_int_p, C.POINTER(C.c_long)]),
         "sparsh_level_layout": (C.c_int, [H, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
-        "sparsh_set_const_slots": (C.c_int, [C.c_int]),
+        "sparsh_set_const_slots": (C.c_int, [H, C.c_int]),
         "sparsh_bench_comm": (C.c_int, [H, C.c_int, C.c_int, C.c_int, c_dbl_p]),
         "sparsh_level_kernel": (C.c_char_p, [H, C.c_int]),
         "sparsh_num_levels": (C.c_int, [H]),
@@ -104,6 +105,7 @@ def _load():
         "sparsh_set_overlap": (C.c_int, [H, C.c_int]),
         "sparsh_comm_group_create": (C.c_int, [C.c_int, P(C.c_void_p)]),
         "sparsh_comm_group_destroy": (None, [C.c_void_p]),
+        "sparsh_comm_group_fail_after": (C.c_int, [C.c_void_p, C.c_int]),
         "sparsh_comm_init_group": (C.c_int, [H, C.c_void_p, C.c_int]),
         "sparsh_dist_local_op": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p]),
         "sparsh_dist_local_op_get": (C.c_int, [H, c_int_p, c_int_p, c_dbl_p, c_int_p, c_int_p, c_int_p, c_int_p]),
@@ -164,16 +166,6 @@ def default_params(**kw) -> Params:
     return p
 
 
-def set_const_slots(enable=True):
-    """Layout option read at setup (process-wide): fold constant diagonals of a slice into one scalar."""
-    _check(lib.sparsh_set_const_slots(int(bool(enable))))
-
-
-def set_kernel_config(kind=3, vec=True, nt=-1, remap=-1):
-    """Select the SpMV-type kernel family (process-wide); see sparsh_set_kernel_config."""
-    _check(lib.sparsh_set_kernel_config(int(kind), int(vec), int(nt), int(remap)))
-
-
 def set_device(device: int):
     _check(lib.sparsh_set_device(device))
 
@@ -192,6 +184,11 @@ def comm_group_create(nranks: int):
 
 def comm_group_destroy(g):
     lib.sparsh_comm_group_destroy(g)
+
+
+def comm_group_fail_after(g, ncalls: int):
+    """Fault injection (tests): every rank's halo exchange number `ncalls` and all later ones fail."""
+    _check(lib.sparsh_comm_group_fail_after(g, int(ncalls)))
 
 
 def device_count() -> int:
@@ -235,6 +232,22 @@ class sp_matrix_mg:
             self.close()
         except Exception:
             pass
+
+    # -- per-handle kernel / layout choices (A/B measurements; results are bitwise identical) -----
+    def set_const_slots(self, enable=True):
+        """Layout option read by setup(): fold constant diagonals of a slice into one scalar."""
+        _check(lib.sparsh_set_const_slots(self._h, int(bool(enable))))
+        return self
+
+    def set_kernel_config(self, kind=3, vec=True, nt=-1, remap=-1):
+        """Select the SpMV-type kernel family of this handle; see sparsh_set_kernel_config."""
+        _check(lib.sparsh_set_kernel_config(self._h, int(kind), int(vec), int(nt), int(remap)))
+        return self
+
+    def level_placement(self, level):
+        nt, remap = C.c_int(0), C.c_int(0)
+        _check(lib.sparsh_level_placement(self._h, level, C.byref(nt), C.byref(remap)))
+        return bool(nt.value), remap.value
 
     # -- setup -----------------------------------------------------------------------------
     def setup(self, params: Params | None = None, host_only: bool = False):

@@ -127,11 +127,14 @@ Mirror &mirror_of(sp_matrix_mg &A, bool need_transpose)
     return *m;
 }
 
-struct CsrKind0 {  // the stand-alone mirrors carry no sliced layouts: run the CSR-stream kernels
-    KernelConfig saved;
-    CsrKind0() : saved(kernel_config()) { kernel_config().kind = 0; }
-    ~CsrKind0() { kernel_config() = saved; }
-};
+// the stand-alone mirrors carry no sliced layouts: run the CSR-stream kernels
+KernelConfig csr_kind0()
+{
+    KernelConfig c;
+    c.kind = 0;
+    return c;
+}
+const KernelConfig kCsr0 = csr_kind0();
 
 void jacobi_device(sp_matrix_mg &A, double *b, double *x, int iteration)
 {
@@ -142,7 +145,6 @@ void jacobi_device(sp_matrix_mg &A, double *b, double *x, int iteration)
     Mirror &m = mirror_of(A, false);
     const size_t n = (size_t)A.nrow;
     DevBuf db(n, b), dx(n, x), dt(n);
-    CsrKind0 guard;
     double *cur = dx.p, *nxt = dt.p;
     int count = 0;
     while (count++ <= iteration) {  // iteration + 1 sweeps, src/AMG_smoothers.cpp:59-60
@@ -152,7 +154,7 @@ void jacobi_device(sp_matrix_mg &A, double *b, double *x, int iteration)
         a.d = m.diag;
         a.y = nxt;
         a.omega = kOmegaJacobi;
-        launch_csr(m.A, OP_JACOBI, a, false, nullptr);
+        launch_csr(m.A, OP_JACOBI, a, false, nullptr, kCsr0);
         std::swap(cur, nxt);
     }
     (void)hipDeviceSynchronize();
@@ -164,12 +166,11 @@ double residual_device(sp_matrix_mg &A, double *b, double *x)
     Mirror &m = mirror_of(A, false);
     const size_t n = (size_t)A.nrow;
     DevBuf db(n, b), dx((size_t)A.ncol, x);
-    CsrKind0 guard;
     CsrArgs a;
     a.x = dx.p;
     a.b = db.p;
     a.partial = m.partial;
-    const int np = launch_csr(m.A, OP_RESNORM, a, false, nullptr);
+    const int np = launch_csr(m.A, OP_RESNORM, a, false, nullptr, kCsr0);
     launch_finalize(FIN_SQRT, m.partial, nullptr, np, m.scal, S_RES, nullptr, 0, nullptr);
     double r = 0.0;
     (void)hipDeviceSynchronize();
@@ -182,12 +183,11 @@ void store_residual_device(sp_matrix_mg &A, double *b, double *x, double *r)
     Mirror &m = mirror_of(A, false);
     const size_t n = (size_t)A.nrow;
     DevBuf db(n, b), dx((size_t)A.ncol, x), dr(n);
-    CsrKind0 guard;
     CsrArgs a;
     a.x = dx.p;
     a.b = db.p;
     a.y = dr.p;
-    launch_csr(m.A, OP_RESID, a, false, nullptr);
+    launch_csr(m.A, OP_RESID, a, false, nullptr, kCsr0);
     dr.get(r, n);
 }
 
@@ -195,11 +195,10 @@ void transfer_residual_device(sp_matrix_mg &P, double *r, double *b)
 {
     Mirror &m = mirror_of(P, true);
     DevBuf dr((size_t)P.nrow, r), dbc((size_t)P.ncol);
-    CsrKind0 guard;
     CsrArgs a;
     a.x = dr.p;
     a.y = dbc.p;
-    launch_csr(m.T, OP_SPMV, a, false, nullptr);
+    launch_csr(m.T, OP_SPMV, a, false, nullptr, kCsr0);
     dbc.get(b, (size_t)P.ncol);
 }
 
@@ -207,11 +206,10 @@ void transfer_solution_device(sp_matrix_mg &P, double *x, double *x1)
 {
     Mirror &m = mirror_of(P, false);
     DevBuf dc((size_t)P.ncol, x), df((size_t)P.nrow, x1);
-    CsrKind0 guard;
     CsrArgs a;
     a.x = dc.p;
     a.y = df.p;
-    launch_csr(m.A, OP_ADD, a, false, nullptr);
+    launch_csr(m.A, OP_ADD, a, false, nullptr, kCsr0);
     df.get(x1, (size_t)P.nrow);
 }
 

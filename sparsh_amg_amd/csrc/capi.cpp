@@ -30,6 +30,13 @@ int fail(int code, const std::string &msg)
     return code;
 }
 
+// end of an operator-level entry point: a fault raised inside the call wins over the copy-back status
+int done(const Engine &E, bool copied_back)
+{
+    if (E.fault() != SPARSH_OK) return fail(E.fault(), E.error);
+    return copied_back ? SPARSH_OK : fail(SPARSH_ENODEV, "D2H failed");
+}
+
 int env_int(const char *name, int dflt)
 {
     const char *v = std::getenv(name);
@@ -62,7 +69,8 @@ struct DBuf {
 
 #define REQUIRE_READY(h)                                                         \
     if (!(h) || !(h)->eng) return fail(SPARSH_EINVAL, "null handle");            \
-    if (!(h)->eng->ready()) return fail(SPARSH_ESTATE, "sparsh_setup has not been called (or failed)")
+    if (!(h)->eng->ready()) return fail(SPARSH_ESTATE, "sparsh_setup has not been called (or failed)"); \
+    if ((h)->eng->fault() != SPARSH_OK) return fail((h)->eng->fault(), (h)->eng->error) /* sticky device / transport fault */
 
 #define REQUIRE_LEVEL(h, l) \
     if ((l) < 0 || (l) >= (int)(h)->eng->host().levels.size()) return fail(SPARSH_EINVAL, "level out of range")
@@ -123,6 +131,22 @@ int sparsh_create_csr(int nrow, int ncol, const int *rowptr, const int *colindex
     if (!out || !rowptr || nrow <= 0 || ncol <= 0) return fail(SPARSH_EINVAL, "bad CSR arguments");
     if (rowptr[0] != 0 || rowptr[nrow] < 0) return fail(SPARSH_EINVAL, "rowptr must start at 0");
     if (rowptr[nrow] > 0 && (!colindex || !val)) return fail(SPARSH_EINVAL, "null colindex/val");
+    // one O(nnz) pass: a non-monotone rowptr or an out-of-range column would become an out-of-bounds
+    // access on the device
+    {
+        long bad_rp = 0, bad_col = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad_rp, bad_col)
+        for (int i = 0; i < nrow; ++i) {
+            const int j0 = rowptr[i], j1 = rowptr[i + 1];
+            if (j1 < j0 || j0 < 0 || j1 > rowptr[nrow]) {
+                ++bad_rp;
+                continue;
+            }
+            for (int j = j0; j < j1; ++j) bad_col += (colindex[j] < 0 || colindex[j] >= ncol);
+        }
+        if (bad_rp) return fail(SPARSH_EINVAL, "rowptr is not monotonically non-decreasing (" + std::to_string(bad_rp) + " rows)");
+        if (bad_col) return fail(SPARSH_EINVAL, "colindex out of range [0, ncol) (" + std::to_string(bad_col) + " entries)");
+    }
     auto *h = new sparsh_handle_s;
     h->eng.reset(new Engine(nrow, ncol, rowptr, colindex, val));
     *out = h;
@@ -166,10 +190,11 @@ int sparsh_set_stopping(sparsh_handle h, double tol, int max_iter, int check_eve
     return SPARSH_OK;
 }
 
-int sparsh_set_kernel_config(int kind, int vec, int nt, int remap)
+int sparsh_set_kernel_config(sparsh_handle h, int kind, int vec, int nt, int remap)
 {
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
     if (kind < 0 || kind > 3) return fail(SPARSH_EINVAL, "kind must be 0 (workgroup CSR-stream), 1 (wave CSR-stream), 2 (sliced ELL) or 3 (sliced diagonals)");
-    KernelConfig &c = kernel_config();
+    KernelConfig &c = h->eng->kernel_cfg();
     c.kind = kind;
     c.vec = vec != 0;
     c.nt = nt > 0;
@@ -186,17 +211,16 @@ int sparsh_level_format(sparsh_handle h, int level, int *kind, long *stored_entr
     REQUIRE_READY(h);
     REQUIRE_LEVEL(h, level);
     const DevCsr &A = h->eng->level(level).A;
-    const KernelConfig &c = kernel_config();
+    const CsrFamily fam = csr_family(A, h->eng->kernel_cfg());  // the launcher's own decision
     int k = 0;
     long e = A.nnz;
-    const bool small_prefers_ell = A.sell_val && A.nrow < 65536 && !(c.table && A.sd_tmask);  // as in launch_csr_tagged
-    if (c.kind == 3 && A.has_sdia() && !small_prefers_ell) {
+    if (fam == FAM_SDIA || fam == FAM_SDIA_TAB) {
         k = 3;
         e = A.sd_vblocks * 64;  // values actually stored: constant slots own no block
-    } else if (c.kind >= 2 && A.sell_val) {
+    } else if (fam == FAM_SELL) {
         k = 2;
         e = A.sell_entries;
-    } else if (c.kind == 1) {
+    } else if (fam == FAM_CSR_WAVE) {
         k = 1;
     }
     if (kind) *kind = k;
@@ -230,12 +254,19 @@ int sparsh_level_layout(sparsh_handle h, int level, long *slots, long *value_blo
 const char *sparsh_level_kernel(sparsh_handle h, int level)
 {
     if (!h || !h->eng || !h->eng->ready() || level < 0 || level >= (int)h->eng->host().levels.size()) return "";
-    const DevCsr &A = h->eng->level(level).A;
-    const KernelConfig &c = kernel_config();
-    if (c.kind == 3 && A.has_sdia() && c.table && A.sd_tmask) return "sdia_tab_kernel";
-    if (c.kind == 3 && A.has_sdia() && !(A.sell_val && A.nrow < 65536)) return "sdia_kernel";
-    if (c.kind >= 2 && A.sell_val) return "sell_kernel";
-    return c.kind == 1 ? "csr_wave_kernel" : "csr_block_kernel";
+    return csr_family_name(csr_family(h->eng->level(level).A, h->eng->kernel_cfg()));
+}
+
+int sparsh_level_placement(sparsh_handle h, int level, int *nt, int *remap)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    bool b = false;
+    int r = 0;
+    csr_placement(h->eng->level(level).A, h->eng->kernel_cfg(), &b, &r);
+    if (nt) *nt = b ? 1 : 0;
+    if (remap) *remap = r;
+    return SPARSH_OK;
 }
 
 int sparsh_bench_comm(sparsh_handle h, int what, int level, int reps, double *avg_seconds)
@@ -246,9 +277,10 @@ int sparsh_bench_comm(sparsh_handle h, int what, int level, int reps, double *av
     return SPARSH_OK;
 }
 
-int sparsh_set_const_slots(int enable)
+int sparsh_set_const_slots(sparsh_handle h, int enable)
 {
-    kernel_config().const_slots = enable != 0;
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    h->eng->kernel_cfg().const_slots = enable != 0;
     return SPARSH_OK;
 }
 
@@ -393,6 +425,13 @@ int sparsh_comm_group_create(int nranks, void **group)
 
 void sparsh_comm_group_destroy(void *group) { thread_group_destroy(static_cast<ThreadGroup *>(group)); }
 
+int sparsh_comm_group_fail_after(void *group, int ncalls)
+{
+    if (!group) return fail(SPARSH_EINVAL, "null group");
+    thread_group_fail_after(static_cast<ThreadGroup *>(group), ncalls);
+    return SPARSH_OK;
+}
+
 int sparsh_comm_init_group(sparsh_handle h, void *group, int rank)
 {
     if (!h || !h->eng || !group) return fail(SPARSH_EINVAL, "bad arguments");
@@ -512,7 +551,7 @@ int sparsh_op_spmv(sparsh_handle h, int level, const double *x, double *y)
     const DevLevel &L = E.level(level);
     DBuf dx(E, (size_t)L.A.ncol, x), dy(E, (size_t)L.n);
     E.op_spmv(level, dx.p, dy.p);
-    return dy.get(y) ? SPARSH_OK : fail(SPARSH_ENODEV, "D2H failed");
+    return done(E, dy.get(y));
 }
 
 int sparsh_op_jacobi(sparsh_handle h, int level, const double *b, double *x, int sweeps, int x_is_zero)
@@ -525,7 +564,7 @@ int sparsh_op_jacobi(sparsh_handle h, int level, const double *b, double *x, int
     const size_t n = (size_t)E.level(level).n;
     DBuf db(E, n, b), dx(E, n, x), dt(E, n);
     E.op_jacobi(level, db.p, dx.p, dt.p, sweeps, x_is_zero != 0);
-    return dx.get(x) ? SPARSH_OK : fail(SPARSH_ENODEV, "D2H failed");
+    return done(E, dx.get(x));
 }
 
 int sparsh_op_residual(sparsh_handle h, int level, const double *b, const double *x, double *r)
@@ -537,7 +576,7 @@ int sparsh_op_residual(sparsh_handle h, int level, const double *b, const double
     const size_t n = (size_t)E.level(level).n;
     DBuf db(E, n, b), dx(E, n, x), dr(E, n);
     E.op_residual(level, db.p, dx.p, dr.p);
-    return dr.get(r) ? SPARSH_OK : fail(SPARSH_ENODEV, "D2H failed");
+    return done(E, dr.get(r));
 }
 
 int sparsh_op_resnorm(sparsh_handle h, int level, const double *b, const double *x, double *nrm)
@@ -561,7 +600,7 @@ int sparsh_op_restrict(sparsh_handle h, int level, const double *r, double *bc)
     Engine &E = *h->eng;
     DBuf dr(E, (size_t)E.level(level).n, r), dc(E, (size_t)E.level(level + 1).n);
     E.op_restrict(level, dr.p, dc.p);
-    return dc.get(bc) ? SPARSH_OK : fail(SPARSH_ENODEV, "D2H failed");
+    return done(E, dc.get(bc));
 }
 
 int sparsh_op_prolong(sparsh_handle h, int level, const double *xc, double *xf)
@@ -573,7 +612,7 @@ int sparsh_op_prolong(sparsh_handle h, int level, const double *xc, double *xf)
     Engine &E = *h->eng;
     DBuf dc(E, (size_t)E.level(level + 1).n, xc), df(E, (size_t)E.level(level).n, xf);
     E.op_prolong(level, dc.p, df.p);
-    return df.get(xf) ? SPARSH_OK : fail(SPARSH_ENODEV, "D2H failed");
+    return done(E, df.get(xf));
 }
 
 int sparsh_op_coarse(sparsh_handle h, const double *b, double *x)
@@ -583,7 +622,7 @@ int sparsh_op_coarse(sparsh_handle h, const double *b, double *x)
     const size_t n = (size_t)E.level(E.nlevels() - 1).n;
     DBuf db(E, n, b), dx(E, n);
     E.op_coarse(db.p, dx.p);
-    return dx.get(x) ? SPARSH_OK : fail(SPARSH_ENODEV, "D2H failed");
+    return done(E, dx.get(x));
 }
 
 int sparsh_op_dot(sparsh_handle h, int n, const double *x, const double *y, double *out)
@@ -613,7 +652,7 @@ int sparsh_op_axpby(sparsh_handle h, int n, double a, const double *x, double bc
     Engine &E = *h->eng;
     DBuf dx(E, (size_t)n, x), dy(E, (size_t)n, y);
     launch_axpby(n, a, dx.p, bcoef, dy.p, E.stream());
-    return dy.get(y) ? SPARSH_OK : fail(SPARSH_ENODEV, "D2H failed");
+    return done(E, dy.get(y));
 }
 
 int sparsh_bench_op(sparsh_handle h, int op, int level, int reps, double *avg_seconds)
@@ -646,7 +685,7 @@ int sparsh_bench_op(sparsh_handle h, int op, int level, int reps, double *avg_se
             a.d = L.diag;
             a.y = y.p;
             a.omega = E.params().omega;
-            launch_csr(L.A, OP_JACOBI, a, L.fine, st);
+            launch_csr(L.A, OP_JACOBI, a, L.fine, st, E.kernel_cfg());
         } break;
         case 2: E.op_residual(level, b.p, x.p, y.p); break;
         case 3: E.op_restrict(level, x.p, c.p); break;

@@ -45,13 +45,15 @@ public:
         if (p.recv.empty() && p.send.empty()) return true;
         if (p.nsend > 0 && p.need_pack) launch_pack(p.nsend, p.send_idx, vec, p.sendbuf, st);
         if (!ok(ncclGroupStart(), "ncclGroupStart")) return false;
+        bool good = true;  // a started group is always ended, also after a failed call inside it
         for (const HaloSeg &s : p.send) {
             const double *src = s.start >= 0 ? vec + s.start : p.sendbuf + s.off;
-            if (!ok(ncclSend(src, (size_t)s.cnt, ncclDouble, s.peer, comm, st), "ncclSend")) return false;
+            if (good) good = ok(ncclSend(src, (size_t)s.cnt, ncclDouble, s.peer, comm, st), "ncclSend");
         }
         for (const HaloSeg &r : p.recv)
-            if (!ok(ncclRecv(vec + p.nloc + r.off, (size_t)r.cnt, ncclDouble, r.peer, comm, st), "ncclRecv")) return false;
-        return ok(ncclGroupEnd(), "ncclGroupEnd");
+            if (good) good = ok(ncclRecv(vec + p.nloc + r.off, (size_t)r.cnt, ncclDouble, r.peer, comm, st), "ncclRecv");
+        const ncclResult_t e = ncclGroupEnd();
+        return good && ok(e, "ncclGroupEnd");
     }
     bool allreduce_sum(double *dev, int n, hipStream_t st) override
     {
@@ -64,13 +66,15 @@ public:
         // -- the same primitives, in the same kind of group, as the halo exchange
         const int mylo = part.lo(rank), mycnt = part.hi(rank) - mylo;
         if (!ok(ncclGroupStart(), "ncclGroupStart")) return false;
+        bool good = true;
         for (int q = 0; q < size; ++q) {
             if (q == rank) continue;
             const int lo = part.lo(q), cnt = part.hi(q) - lo;
-            if (mycnt > 0 && !ok(ncclSend(full + mylo, (size_t)mycnt, ncclDouble, q, comm, st), "ncclSend")) return false;
-            if (cnt > 0 && !ok(ncclRecv(full + lo, (size_t)cnt, ncclDouble, q, comm, st), "ncclRecv")) return false;
+            if (good && mycnt > 0) good = ok(ncclSend(full + mylo, (size_t)mycnt, ncclDouble, q, comm, st), "ncclSend");
+            if (good && cnt > 0) good = ok(ncclRecv(full + lo, (size_t)cnt, ncclDouble, q, comm, st), "ncclRecv");
         }
-        return ok(ncclGroupEnd(), "ncclGroupEnd");
+        const ncclResult_t e = ncclGroupEnd();
+        return good && ok(e, "ncclGroupEnd");
     }
     bool barrier(hipStream_t st) override
     {
@@ -123,6 +127,7 @@ struct ThreadGroup {
     std::vector<hipEvent_t> pub, done;  // per rank: "my boundary data is ready" / "my pulls are finished"
     std::vector<double *> ptrs;
     std::vector<std::vector<double>> host;
+    int fail_after = -1;  // test hook: every rank's exchange() number fail_after (0-based) and later ones fail
     void wait()
     {
         std::unique_lock<std::mutex> lk(m);
@@ -150,6 +155,11 @@ ThreadGroup *thread_group_create(int nranks)
     return g;
 }
 
+void thread_group_fail_after(ThreadGroup *g, int n)
+{
+    if (g) g->fail_after = n;
+}
+
 void thread_group_destroy(ThreadGroup *g)
 {
     if (!g) return;
@@ -168,8 +178,15 @@ public:
     // event handles; all data movement and all ordering is expressed with stream events, exactly as
     // the engine has to express it for RCCL.  A missing dependency in the engine (e.g. a kernel that
     // does not wait for the halo) therefore shows up as wrong data in the virtual-rank tests.
+    int calls = 0;
     bool exchange(const DevPlan &p, double *vec, hipStream_t st) override
     {
+        // injected transport failure (tests): all ranks count the same call sequence, so all of them
+        // fail at the same call and nobody is left waiting at a rendezvous
+        if (g->fail_after >= 0 && calls++ >= g->fail_after) {
+            error = "injected transport failure (test hook)";
+            return false;
+        }
         if (!g->pub[rank]) {
             (void)hipEventCreateWithFlags(&g->pub[rank], hipEventDisableTiming);
             (void)hipEventCreateWithFlags(&g->done[rank], hipEventDisableTiming);

@@ -52,6 +52,7 @@ std::unique_ptr<Comm> make_rccl_comm(const char id[128], int rank, int nranks, s
 struct ThreadGroup;
 ThreadGroup *thread_group_create(int nranks);
 void thread_group_destroy(ThreadGroup *g);
+void thread_group_fail_after(ThreadGroup *g, int n);  // test hook: exchanges from call n on fail on every rank
 std::unique_ptr<Comm> make_thread_comm(ThreadGroup *g, int rank);
 
 }  // namespace sparsh

@@ -32,6 +32,28 @@ bool Engine::check(hipError_t e, const char *what)
     return false;
 }
 
+bool Engine::note_hip(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return true;
+    if (fault_ == SPARSH_OK) {
+        fault_ = SPARSH_ENODEV;
+        error = std::string("HIP error on the solve path: ") + what + ": " + hipGetErrorString(e);
+    }
+    return false;
+}
+
+bool Engine::note_comm(bool ok, const char *what)
+{
+    if (ok) return true;
+    if (fault_ == SPARSH_OK) {
+        fault_ = SPARSH_ECOMM;
+        error = std::string(what) + " failed: " + (comm_ ? comm_->error : std::string("no transport"));
+    }
+    return false;
+}
+
+#define HIPCHK(call) note_hip((call), #call)
+
 void *Engine::dalloc(size_t bytes)
 {
     void *p = nullptr;
@@ -198,7 +220,7 @@ bool upload_sdia(Engine &E, const HostCsr &A, DevCsr &D)
     // drop the 64-value block (the product v*x is the same multiplication, so results do not change)
     std::vector<int> vidx((size_t)total, 0);
     std::vector<double> cval((size_t)total, 0.0);
-    const bool fold = kernel_config().const_slots && !E.params().precond_fp32;  // the float mirror converts whole blocks
+    const bool fold = E.kernel_cfg().const_slots && !E.params().precond_fp32;  // the float mirror converts whole blocks
 #pragma omp parallel for schedule(static)
     for (long q = 0; q < total; ++q) {
         const unsigned long long m = mask[(size_t)q];
@@ -422,6 +444,7 @@ int Engine::setup(const sparsh_params &p)
 {
     prm_ = p;
     ready_ = false;
+    fault_ = SPARSH_OK;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         error = "no HIP device visible: the MI355X HIP path is the only compute path (no CPU fallback)";
@@ -525,9 +548,9 @@ int Engine::setup(const sparsh_params &p)
         if (!d.diag || !d.x || !d.x2 || !d.r || (l > 0 && !d.b)) return SPARSH_ENODEV;
         if (l + 1 < nl) max_blk = std::max(max_blk, std::max(partial_count(d.P), partial_count(d.R)));
         max_blk = std::max(max_blk, partial_count(d.A));
-        (void)hipMemsetAsync(d.x, 0, xcap * 8, st_);
-        (void)hipMemsetAsync(d.x2, 0, xcap * 8, st_);
-        (void)hipMemsetAsync(d.r, 0, rcap * 8, st_);
+        if (!check(hipMemsetAsync(d.x, 0, xcap * 8, st_), "hipMemsetAsync")) return SPARSH_ENODEV;
+        if (!check(hipMemsetAsync(d.x2, 0, xcap * 8, st_), "hipMemsetAsync")) return SPARSH_ENODEV;
+        if (!check(hipMemsetAsync(d.r, 0, rcap * 8, st_), "hipMemsetAsync")) return SPARSH_ENODEV;
     }
     nL_ = H_.nL;
     if (H_.coarse_dense) {
@@ -554,8 +577,8 @@ int Engine::setup(const sparsh_params &p)
     hist_dev_ = static_cast<double *>(dalloc((size_t)hist_cap_dev_ * 8));
     iter_ctr_ = static_cast<int *>(dalloc(sizeof(int)));
     if (!part0_ || !part1_ || !scal_ || !hist_dev_ || !iter_ctr_) return SPARSH_ENODEV;
-    (void)hipMemsetAsync(scal_, 0, S_COUNT * 8, st_);
-    (void)hipMemsetAsync(iter_ctr_, 0, sizeof(int), st_);
+    if (!check(hipMemsetAsync(scal_, 0, S_COUNT * 8, st_), "hipMemsetAsync")) return SPARSH_ENODEV;
+    if (!check(hipMemsetAsync(iter_ctr_, 0, sizeof(int), st_), "hipMemsetAsync")) return SPARSH_ENODEV;
     drop_graph();  // a captured iteration refers to the buffers of the previous setup
     if (!pinned_ && !check(hipHostMalloc(reinterpret_cast<void **>(&pinned_), 64 * sizeof(double), hipHostMallocDefault), "hipHostMalloc"))
         return SPARSH_ENODEV;
@@ -564,7 +587,7 @@ int Engine::setup(const sparsh_params &p)
     for (int k = 0; k < 8; ++k) {
         double *w = static_cast<double *>(dalloc(wcap * 8));
         if (!w) return SPARSH_ENODEV;
-        (void)hipMemsetAsync(w, 0, wcap * 8, st_);
+        if (!check(hipMemsetAsync(w, 0, wcap * 8, st_), "hipMemsetAsync")) return SPARSH_ENODEV;
         work_.push_back(w);
     }
     f32_ready_ = false;
@@ -687,15 +710,15 @@ void Engine::vcycle_f32(const double *r64, double *z64, double *partial, int *nb
 
 double Engine::read_scalar(int slot)
 {
-    (void)hipMemcpyAsync(pinned_, scal_ + slot, sizeof(double), hipMemcpyDeviceToHost, st_);
-    (void)hipStreamSynchronize(st_);
+    HIPCHK(hipMemcpyAsync(pinned_, scal_ + slot, sizeof(double), hipMemcpyDeviceToHost, st_));
+    HIPCHK(hipStreamSynchronize(st_));
     return pinned_[0];
 }
 
 double Engine::read_hist(int it)
 {
-    (void)hipMemcpyAsync(pinned_, hist_dev_ + it, sizeof(double), hipMemcpyDeviceToHost, st_);
-    (void)hipStreamSynchronize(st_);
+    HIPCHK(hipMemcpyAsync(pinned_, hist_dev_ + it, sizeof(double), hipMemcpyDeviceToHost, st_));
+    HIPCHK(hipStreamSynchronize(st_));
     return pinned_[0];
 }
 
@@ -704,11 +727,7 @@ double Engine::read_hist(int it)
 bool Engine::halo(const DevPlan &p, double *vec)
 {
     if (!dist_) return true;
-    if (!comm_->exchange(p, vec, st_)) {
-        error = "halo exchange failed: " + comm_->error;
-        return false;
-    }
-    return true;
+    return note_comm(comm_->exchange(p, vec, st_), "halo exchange");
 }
 
 double Engine::bench_comm(int what, int level, int reps)
@@ -725,45 +744,45 @@ double Engine::bench_comm(int what, int level, int reps)
     for (int i = 0; i < 3; ++i)
         if (!step()) return -1.0;
     hipEvent_t e0, e1;
-    (void)hipEventCreate(&e0);
-    (void)hipEventCreate(&e1);
-    (void)hipEventRecord(e0, st_);
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, st_));
     bool ok = true;
     for (int i = 0; i < reps && ok; ++i) ok = step();
-    (void)hipEventRecord(e1, st_);
-    (void)hipEventSynchronize(e1);
+    HIPCHK(hipEventRecord(e1, st_));
+    HIPCHK(hipEventSynchronize(e1));
     float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    HIPCHK(hipEventDestroy(e0));
+    HIPCHK(hipEventDestroy(e1));
     return ok ? ms * 1e-3 / reps : -1.0;
 }
 
 int Engine::apply_A(DevLevel &L, CsrOp op, CsrArgs a)
 {
     double *xin = const_cast<double *>(a.x);
-    const KernelConfig &kc = kernel_config();
-    const bool sliced = (kc.kind == 3 && L.A.has_sdia()) || (kc.kind >= 2 && L.A.sell_val);
+    const CsrFamily fam = csr_family(L.A, cfg_);
+    const bool sliced = fam == FAM_SDIA || fam == FAM_SDIA_TAB || fam == FAM_SELL;
     if (!(dist_ && overlap_ && !L.replicated && sliced && L.A.nint > 0 && L.A.nbnd > 0 && st2_)) {
-        halo(L.planA, xin);
-        return launch_csr(L.A, op, a, L.fine, st_);
+        if (!halo(L.planA, xin)) return 0;  // transport failed: sticky fault, nothing launched on stale data
+        return launch_csr(L.A, op, a, L.fine, st_, cfg_);
     }
     // overlap: [st2] wait until x is final -> pack + exchange ; [st] interior slices meanwhile ;
     //          [st] wait for the halo -> boundary slices
-    (void)hipEventRecord(ev_ready_, st_);
-    (void)hipStreamWaitEvent(st2_, ev_ready_, 0);
+    HIPCHK(hipEventRecord(ev_ready_, st_));
+    HIPCHK(hipStreamWaitEvent(st2_, ev_ready_, 0));
     const DevPlan &p = L.planA;
-    if (!comm_->exchange(p, xin, st2_)) error = "halo exchange failed: " + comm_->error;
-    (void)hipEventRecord(ev_halo_, st2_);
+    note_comm(comm_->exchange(p, xin, st2_), "halo exchange");
+    HIPCHK(hipEventRecord(ev_halo_, st2_));
     a.slice_list = L.A.int_list;
     a.nlist = L.A.nint;
     a.partial_off = 0;
-    const int n1 = launch_csr(L.A, op, a, L.fine, st_);
-    (void)hipStreamWaitEvent(st_, ev_halo_, 0);
+    const int n1 = launch_csr(L.A, op, a, L.fine, st_, cfg_);
+    HIPCHK(hipStreamWaitEvent(st_, ev_halo_, 0));
     a.slice_list = L.A.bnd_list;
     a.nlist = L.A.nbnd;
     a.partial_off = n1;
-    const int n2 = launch_csr(L.A, op, a, L.fine, st_);
+    const int n2 = launch_csr(L.A, op, a, L.fine, st_, cfg_);
     return n1 + n2;
 }
 
@@ -776,7 +795,7 @@ void Engine::finalize(Fin code, const double *p0, const double *p1, int nblk, in
         return;
     }
     launch_finalize(code, p0, p1, nblk, scal_, slot, hist, it, st_, 1, iter_ctr_, hist_cap_dev_, nblk1);
-    if (!comm_->allreduce_sum(scal_ + S_SUM0, 2, st_)) error = "allreduce failed: " + comm_->error;
+    note_comm(comm_->allreduce_sum(scal_ + S_SUM0, 2, st_), "allreduce");
     launch_finalize(code, p0, p1, nblk, scal_, slot, hist, it, st_, 2, iter_ctr_, hist_cap_dev_, nblk1);
 }
 
@@ -823,8 +842,8 @@ void Engine::op_restrict(int l, const double *r, double *bc)
     if (L.P_is_aggregation)
         launch_restrict_agg(L.R.nrow, L.R.rowptr, L.R.col, r, a.y, st_);
     else
-        launch_csr(L.R, OP_SPMV, a, false, st_);
-    if (gather && !comm_->allgather(bc, gather_part_, st_)) error = "allgather failed: " + comm_->error;
+        launch_csr(L.R, OP_SPMV, a, false, st_, cfg_);
+    if (gather) note_comm(comm_->allgather(bc, gather_part_, st_), "allgather");
 }
 
 void Engine::op_prolong(int l, const double *xc, double *xf)
@@ -837,7 +856,7 @@ void Engine::op_prolong(int l, const double *xc, double *xf)
         CsrArgs a;
         a.x = xc;
         a.y = xf;
-        launch_csr(L.P, OP_ADD, a, false, st_);
+        launch_csr(L.P, OP_ADD, a, false, st_, cfg_);
     }
 }
 
@@ -877,10 +896,10 @@ void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, doubl
             dot_done = true;
         }
         const bool rec = timed && prof.used + 2 <= prof.ev.size();
-        if (rec) (void)hipEventRecord(prof.ev[prof.used++], st_);
+        if (rec) HIPCHK(hipEventRecord(prof.ev[prof.used++], st_));
         const int np = apply_A(L, op, a);
         if (op == OP_JACOBI_DOT) *dot_nblk = np;
-        if (rec) (void)hipEventRecord(prof.ev[prof.used++], st_);
+        if (rec) HIPCHK(hipEventRecord(prof.ev[prof.used++], st_));
         std::swap(L.x, L.x2);
     }
     if (dot_partial && !dot_done) launch_dot(L.n, L.x, b, dot_partial, dot_nblk, st_);
@@ -931,7 +950,7 @@ int Engine::amg_solve_dev(const double *b, double *x, int iterations, double *hi
     if (!ready_) return SPARSH_ESTATE;
     DevLevel &L0 = lev_[0];
     const int n = L0.n;
-    (void)hipMemcpyAsync(L0.x, x, (size_t)n * 8, hipMemcpyDeviceToDevice, st_);
+    HIPCHK(hipMemcpyAsync(L0.x, x, (size_t)n * 8, hipMemcpyDeviceToDevice, st_));
     int cycles = 0;
     double r1 = op_resnorm(0, b, L0.x);
     int rc = SPARSH_OK;
@@ -942,9 +961,9 @@ int Engine::amg_solve_dev(const double *b, double *x, int iterations, double *hi
         if (hist && cycles - 1 < hist_cap) hist[cycles - 1] = r1;
     };
     if (iterations > 0) {
-        while (cycles < iterations) one_cycle();
+        while (cycles < iterations && fault_ == SPARSH_OK) one_cycle();
     } else if (iterations == -1) {
-        while (r1 > prm_.tol) {
+        while (r1 > prm_.tol && fault_ == SPARSH_OK) {
             if (cycles >= prm_.max_iter) {
                 rc = SPARSH_ENOCONV;
                 break;
@@ -957,10 +976,10 @@ int Engine::amg_solve_dev(const double *b, double *x, int iterations, double *hi
             }
         }
     }
-    (void)hipMemcpyAsync(x, lev_[0].x, (size_t)n * 8, hipMemcpyDeviceToDevice, st_);
-    (void)hipStreamSynchronize(st_);
+    HIPCHK(hipMemcpyAsync(x, lev_[0].x, (size_t)n * 8, hipMemcpyDeviceToDevice, st_));
+    HIPCHK(hipStreamSynchronize(st_));
     if (ncycles) *ncycles = cycles;
-    return rc;
+    return fault_ != SPARSH_OK ? fault_ : rc;
 }
 
 // Solver_CG_1 (precond = false) / Solver_PCG_1 (precond = true), split into the part before
@@ -997,7 +1016,7 @@ int Engine::pcg_init(const double *b, double *x, bool precond)
         launch_copy(n, r, p, st_);
     }
     ks_.active = true;
-    return SPARSH_OK;
+    return fault_;
 }
 
 // One pass of the loop body of Solver_PCG_1 / Solver_CG_1 (src/AMG_main_solvers.cpp:138-152,
@@ -1036,8 +1055,8 @@ void Engine::pcg_body(bool precond, int slot)
 
 void Engine::drop_graph()
 {
-    if (graph_.exec) (void)hipGraphExecDestroy(graph_.exec);
-    if (graph_.graph) (void)hipGraphDestroy(graph_.graph);
+    if (graph_.exec) HIPCHK(hipGraphExecDestroy(graph_.exec));
+    if (graph_.graph) HIPCHK(hipGraphDestroy(graph_.graph));
     graph_ = GraphState();
 }
 
@@ -1054,7 +1073,7 @@ bool Engine::capture_graph(bool precond)
     if (hipStreamEndCapture(st_, &g) != hipSuccess || !g) return false;
     hipGraphExec_t e = nullptr;
     if (hipGraphInstantiate(&e, g, nullptr, nullptr, 0) != hipSuccess) {
-        (void)hipGraphDestroy(g);
+        HIPCHK(hipGraphDestroy(g));
         return false;
     }
     graph_.graph = g;
@@ -1077,13 +1096,13 @@ int Engine::pcg_steps(int nsteps, int *done)
     // hipGraph replay: single GPU, no per-launch profiling events
     bool use_graph = prm_.use_graph && !dist_ && !prof.enabled && (int)lev_.size() > 1;
     if (use_graph && !(graph_.exec && graph_.x == ks_.x && graph_.precond == precond)) use_graph = capture_graph(precond);
-    if (use_graph) (void)hipMemcpyAsync(iter_ctr_, &ks_.count, sizeof(int), hipMemcpyHostToDevice, st_);
-    while (ks_.count < lev_[0].nglob && ks_.r1 > prm_.tol && did < nsteps) {
+    if (use_graph) HIPCHK(hipMemcpyAsync(iter_ctr_, &ks_.count, sizeof(int), hipMemcpyHostToDevice, st_));
+    while (ks_.count < lev_[0].nglob && ks_.r1 > prm_.tol && did < nsteps && fault_ == SPARSH_OK) {
         const int count = ++ks_.count;
         ++did;
         const int slot = std::min(count - 1, hist_cap_dev_ - 1);
         if (use_graph)
-            (void)hipGraphLaunch(graph_.exec, st_);
+            HIPCHK(hipGraphLaunch(graph_.exec, st_));
         else
             pcg_body(precond, slot);
         if (count % check_every == 0 || did >= nsteps) {
@@ -1096,14 +1115,14 @@ int Engine::pcg_steps(int nsteps, int *done)
         }
     }
     if (done) *done = did;
-    return rc;
+    return fault_ != SPARSH_OK ? fault_ : rc;
 }
 
 int Engine::krylov_hist(double *hist, int hist_cap)
 {
-    (void)hipStreamSynchronize(st_);
+    HIPCHK(hipStreamSynchronize(st_));
     const int m = std::min(std::min(ks_.count, hist_cap), hist_cap_dev_);
-    if (hist && m > 0) (void)hipMemcpy(hist, hist_dev_, (size_t)m * 8, hipMemcpyDeviceToHost);
+    if (hist && m > 0) HIPCHK(hipMemcpy(hist, hist_dev_, (size_t)m * 8, hipMemcpyDeviceToHost));
     return ks_.count;
 }
 
@@ -1114,6 +1133,7 @@ int Engine::pcg(const double *b, double *x, int max_iters, double *hist, int his
     int did = 0;
     rc = pcg_steps(max_iters, &did);
     if (rc == SPARSH_OK && ks_.r1 > prm_.tol && ks_.count < lev_[0].nglob) rc = SPARSH_ENOCONV;
+    if (fault_ != SPARSH_OK) rc = fault_;
     const int count = krylov_hist(hist, hist_cap);
     if (iters) *iters = count;
     ks_.active = false;
@@ -1141,6 +1161,7 @@ int Engine::bicg(const double *b, double *x, int max_iters, double *hist, int hi
     int rc = SPARSH_OK;
     const int check_every = std::max(1, prm_.check_every);
     while (res > prm_.tol) {
+        if (fault_ != SPARSH_OK) break;
         if (count >= max_iters) {
             rc = SPARSH_ENOCONV;
             break;
@@ -1183,20 +1204,20 @@ int Engine::bicg(const double *b, double *x, int max_iters, double *hist, int hi
             }
         }
     }
-    (void)hipStreamSynchronize(st_);
+    HIPCHK(hipStreamSynchronize(st_));
     if (hist) {
         const int m = std::min(std::min(count, hist_cap), hist_cap_dev_);
-        if (m > 0) (void)hipMemcpy(hist, hist_dev_, (size_t)m * 8, hipMemcpyDeviceToHost);
+        if (m > 0) HIPCHK(hipMemcpy(hist, hist_dev_, (size_t)m * 8, hipMemcpyDeviceToHost));
     }
     if (iters) *iters = count;
-    return rc;
+    return fault_ != SPARSH_OK ? fault_ : rc;
 }
 
 void Engine::profile_begin()
 {
     if (prof.ev.empty()) {
         prof.ev.resize(kProfEvents);
-        for (auto &e : prof.ev) (void)hipEventCreate(&e);
+        for (auto &e : prof.ev) HIPCHK(hipEventCreate(&e));
     }
     prof.used = 0;
     prof.launches = 0;
@@ -1205,7 +1226,7 @@ void Engine::profile_begin()
 
 void Engine::profile_collect()
 {
-    if (st_) (void)hipStreamSynchronize(st_);
+    if (st_) HIPCHK(hipStreamSynchronize(st_));
     prof.launches = 0;
     prof.seconds = 0;
     for (size_t k = 0; k + 1 < prof.used; k += 2) {
@@ -1223,13 +1244,14 @@ int Engine::solve_dev(int method, const double *b, double *x, int max_iters, dou
         error = "sparsh_setup has not been called";
         return SPARSH_ESTATE;
     }
+    if (fault_ != SPARSH_OK) return fault_;  // sticky: a failed device/transport step leaves undefined state behind
     if (max_iters <= 0) max_iters = prm_.max_iter;
     if (prof.enabled) profile_begin();
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (seconds) {
-        (void)hipEventCreate(&e0);
-        (void)hipEventCreate(&e1);
-        (void)hipEventRecord(e0, st_);
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, st_));
     }
     int rc;
     switch (method) {
@@ -1244,20 +1266,17 @@ int Engine::solve_dev(int method, const double *b, double *x, int max_iters, dou
     default: error = "unknown method"; return SPARSH_EINVAL;
     }
     if (seconds) {
-        (void)hipEventRecord(e1, st_);
-        (void)hipEventSynchronize(e1);
+        HIPCHK(hipEventRecord(e1, st_));
+        HIPCHK(hipEventSynchronize(e1));
         float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
         *seconds = ms * 1e-3;
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
+        HIPCHK(hipEventDestroy(e0));
+        HIPCHK(hipEventDestroy(e1));
     }
     if (prof.enabled) profile_collect();
-    hipError_t le = hipGetLastError();
-    if (le != hipSuccess) {
-        error = std::string("HIP error during solve: ") + hipGetErrorString(le);
-        return SPARSH_ENODEV;
-    }
+    note_hip(hipGetLastError(), "kernel launch during the solve");
+    if (fault_ != SPARSH_OK) return fault_;
     if (rc == SPARSH_ENOCONV) error = "iteration cap reached before ||r|| <= tol";
     if (rc == SPARSH_ENUMERIC) error = "NaN residual";
     return rc;

@@ -72,6 +72,9 @@ public:
     const HostHierarchy &host() const { return H_; }
     const CoarseSolver &coarse() const { return coarse_; }
     const sparsh_params &params() const { return prm_; }
+    // kernel-family / layout choices of THIS handle (const_slots is read when the layouts are built)
+    KernelConfig &kernel_cfg() { return cfg_; }
+    const KernelConfig &kernel_cfg() const { return cfg_; }
     // average seconds of one communication step alone (collective: every rank calls it): what = 0 halo
     // exchange of level `level`'s operator, 1 the 16-byte all-reduce of the fused scalars, 2 the
     // all-gather at the partitioned -> replicated boundary.  -1 when the step does not exist.
@@ -121,6 +124,12 @@ public:
     void dfree(void *p);
     bool check(hipError_t e, const char *what);
     std::string error;
+    // Sticky fault of the solve path: the first failed HIP call (SPARSH_ENODEV) or transport step
+    // (SPARSH_ECOMM) since setup.  Solvers stop at their next check and return it; every later
+    // call on the handle returns it too until sparsh_setup is called again.
+    int fault() const { return fault_; }
+    bool note_hip(hipError_t e, const char *what);
+    bool note_comm(bool ok, const char *what);
 
     ProfileData prof;
     void profile_begin();    // (re)arm the event pool
@@ -167,6 +176,7 @@ private:
     HostCsr A0_;
     HostHierarchy H_;
     sparsh_params prm_{};
+    KernelConfig cfg_;
     std::vector<DevLevel> lev_;
     CoarseSolver coarse_;  // coarsest-level direct solver (dense inverse or block-tridiagonal factors)
     double *coarse_tmp_ = nullptr;  // fp32 mode with the block-tridiagonal form: fp64 staging of b_L, x_L
@@ -174,6 +184,7 @@ private:
     hipStream_t st_ = nullptr;
     bool ready_ = false;
     bool host_ready_ = false;
+    int fault_ = 0;
     int device_ = 0;
 
     // workspace

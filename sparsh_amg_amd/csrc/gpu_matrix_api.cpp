@@ -83,8 +83,8 @@ void sp_matrix_gpu::smooth_jacobi(double *bgpu, double *xgpu, double *hgpu, hipS
         std::cout << "sparsh: smooth_jacobi needs matrix_transfer_gpu of a square matrix first" << std::endl;
         return;
     }
-    KernelConfig saved = kernel_config();
-    kernel_config().kind = 0;  // stand-alone operator: CSR-stream kernels (no mirror layouts built)
+    KernelConfig kc;
+    kc.kind = 0;  // stand-alone operator: CSR-stream kernels (no mirror layouts built)
     double *cur = xgpu, *nxt = hgpu;
     for (int k = 0; k < steps; ++k) {
         CsrArgs a;
@@ -93,11 +93,10 @@ void sp_matrix_gpu::smooth_jacobi(double *bgpu, double *xgpu, double *hgpu, hipS
         a.d = diag;
         a.y = nxt;
         a.omega = kOmegaJacobi;
-        launch_csr(g->D, OP_JACOBI, a, false, streams);
+        launch_csr(g->D, OP_JACOBI, a, false, streams, kc);
         std::swap(cur, nxt);
     }
     if (cur != xgpu) launch_copy(nrow, cur, xgpu, streams);
-    kernel_config() = saved;
 }
 
 sp_matrix_gpu::~sp_matrix_gpu()
@@ -137,14 +136,13 @@ double residual(sp_matrix_gpu &A, double *b, double *x, double *h, hipStream_t s
         std::cout << "sparsh: residual needs matrix_transfer_gpu first" << std::endl;
         return NAN;
     }
-    KernelConfig saved = kernel_config();
-    kernel_config().kind = 0;
+    KernelConfig kc;
+    kc.kind = 0;
     CsrArgs a;
     a.x = x;
     a.b = b;
     a.partial = g->partial;
-    const int np = launch_csr(g->D, OP_RESNORM, a, false, streams);
-    kernel_config() = saved;
+    const int np = launch_csr(g->D, OP_RESNORM, a, false, streams, kc);
     launch_finalize(FIN_SQRT, g->partial, nullptr, np, g->scal, S_RES, nullptr, 0, streams);
     (void)hipMemcpyAsync(g->pinned, g->scal + S_RES, sizeof(double), hipMemcpyDeviceToHost, streams);
     (void)hipStreamSynchronize(streams);

@@ -1027,13 +1027,11 @@ __global__ __launch_bounds__(kBlock) void cvt_f2d_dot_kernel(int n, const float 
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
-KernelConfig g_cfg;
-
 template <int OP, int TAG>
-int launch_csr_tagged(const DevCsr &A, const CsrArgs &a, bool nt, int remap, hipStream_t st)
+int launch_csr_tagged(const DevCsr &A, const CsrArgs &a, bool nt, int remap, hipStream_t st, const KernelConfig &c)
 {
-    const KernelConfig &c = g_cfg;
-    if (c.kind == 3 && A.has_sdia() && c.table && A.sd_tmask) {
+    const CsrFamily fam = csr_family(A, c);
+    if (fam == FAM_SDIA_TAB) {
         const int nwork = a.slice_list ? a.nlist : A.nslice;
         const int ngroups = (nwork + 3) / 4;
         if (ngroups <= 0) return 0;
@@ -1044,10 +1042,7 @@ int launch_csr_tagged(const DevCsr &A, const CsrArgs &a, bool nt, int remap, hip
             hipLaunchKernelGGL((sdia_tab_kernel<OP, false, TAG>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.ncol, nwork, ngroups, remap, A.sd_tab, a.slice_list, A.sd_tmask, A.sd_tconf, A.sd_ptr, A.sd_off, A.sd_mask, A.sd_vidx, A.sd_cval, A.sd_val, A.sd_rec, a);
         return ngroups;
     }
-    // a small level without a stencil table is latency-bound by the slot-header chain of sdia_kernel
-    // (9842-row level of the 216^3 hierarchy: 5.5 us per sweep against 3.1 us for the sliced-ELL kernel)
-    const bool small_prefers_ell = A.sell_val && A.nrow < 65536;
-    if (c.kind == 3 && A.has_sdia() && !small_prefers_ell) {
+    if (fam == FAM_SDIA) {
         const int ngroups = ((a.slice_list ? a.nlist : A.nslice) + 3) / 4;
         if (ngroups <= 0) return 0;
         const int grid = remap_grid(ngroups, remap);
@@ -1057,7 +1052,7 @@ int launch_csr_tagged(const DevCsr &A, const CsrArgs &a, bool nt, int remap, hip
             hipLaunchKernelGGL((sdia_kernel<OP, false, TAG>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.nslice, ngroups, remap, A.sd_ptr, A.sd_off, A.sd_mask, A.sd_vidx, A.sd_cval, A.sd_val, A.sd_rec, a);
         return ngroups;
     }
-    if (c.kind >= 2 && A.sell_val) {
+    if (fam == FAM_SELL) {
         const int ngroups = ((a.slice_list ? a.nlist : A.nslice) + 3) / 4;
         if (ngroups <= 0) return 0;
         const int grid = remap_grid(ngroups, remap);
@@ -1067,7 +1062,7 @@ int launch_csr_tagged(const DevCsr &A, const CsrArgs &a, bool nt, int remap, hip
             hipLaunchKernelGGL((sell_kernel<OP, false, TAG>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.nslice, ngroups, remap, A.slice_ptr, A.rowptr, A.sell_col, A.sell_val, a);
         return ngroups;
     }
-    if (c.kind == 1 && A.waveblk) {
+    if (fam == FAM_CSR_WAVE) {
         const int ngroups = (A.nwblk + 3) / 4;
         if (ngroups <= 0) return 0;
         const int grid = remap_grid(ngroups, remap);
@@ -1092,12 +1087,36 @@ int launch_csr_tagged(const DevCsr &A, const CsrArgs &a, bool nt, int remap, hip
     return A.nblk;
 }
 
-template <int OP>
-int launch_csr_op(const DevCsr &A, const CsrArgs &a, bool finest, hipStream_t st)
+}  // namespace
+
+CsrFamily csr_family(const DevCsr &A, const KernelConfig &c)
 {
-    const KernelConfig &c = g_cfg;
+    if (c.kind == 3 && A.has_sdia() && c.table && A.sd_tmask) return FAM_SDIA_TAB;
+    // a small level without a stencil table is latency-bound by the slot-header chain of sdia_kernel
+    // (9842-row level of the 216^3 hierarchy: 5.5 us per sweep against 3.1 us for the sliced-ELL kernel)
+    const bool small_prefers_ell = A.sell_val && A.nrow < 65536;
+    if (c.kind == 3 && A.has_sdia() && !small_prefers_ell) return FAM_SDIA;
+    if (c.kind >= 2 && A.sell_val) return FAM_SELL;
+    if (c.kind == 1 && A.waveblk) return FAM_CSR_WAVE;
+    return FAM_CSR_BLOCK;
+}
+
+const char *csr_family_name(CsrFamily f)
+{
+    switch (f) {
+    case FAM_SDIA_TAB: return "sdia_tab_kernel";
+    case FAM_SDIA: return "sdia_kernel";
+    case FAM_SELL: return "sell_kernel";
+    case FAM_CSR_WAVE: return "csr_wave_kernel";
+    default: return "csr_block_kernel";
+    }
+}
+
+void csr_placement(const DevCsr &A, const KernelConfig &c, bool *nt_out, int *remap_out)
+{
     bool nt = c.nt;
     int remap = c.remap;
+    const CsrFamily fam = csr_family(A, c);
     if (c.auto_policy) {
         // measured on MI355X (profiles/r01_remap_sweep.txt, r01_remap_sweep_sdia.txt): what decides is
         // whether one sweep's working set -- the bytes of the layout actually used plus the
@@ -1105,14 +1124,14 @@ int launch_csr_op(const DevCsr &A, const CsrArgs &a, bool finest, hipStream_t st
         // default cache policy, one contiguous eighth of the rows per XCD.  If not: non-temporal
         // matrix stream and all XCDs sweeping one neighbourhood (groups of 16 row blocks).
         size_t bytes;
-        if (c.kind == 3 && A.has_sdia())
+        if (fam == FAM_SDIA || fam == FAM_SDIA_TAB)
             bytes = (size_t)A.sd_vblocks * 64 * 8 + (size_t)A.nrow * 24 +
                     (A.sd_tmask ? (size_t)A.nslice * 68 : (A.sd_rec ? (size_t)A.nslice * kSdRecInts * 4 : (size_t)A.sd_slots * 24));
-        else if (c.kind >= 2 && A.sell_val)
+        else if (fam == FAM_SELL)
             bytes = (size_t)A.sell_entries * 12 + (size_t)A.nrow * 28;
         else
             bytes = (size_t)A.nnz * 12 + (size_t)A.nrow * 36;
-        if (c.kind == 3 && A.has_sdia() && c.table && A.sd_tmask) {
+        if (fam == FAM_SDIA_TAB) {
             // table path: no matrix stream to keep out of the caches; a contiguous eighth per XCD
             // reads x 1.2x instead of 3.3x and wins inside the solve at every size (216^3: 395 vs
             // 380 it/s, finest-level sweep 58 vs 65 us; profiles/r01_table_placement_in_solve.txt)
@@ -1126,7 +1145,19 @@ int launch_csr_op(const DevCsr &A, const CsrArgs &a, bool finest, hipStream_t st
             remap = 1;
         }
     }
-    return finest ? launch_csr_tagged<OP, 1>(A, a, nt, remap, st) : launch_csr_tagged<OP, 0>(A, a, nt, remap, st);
+    *nt_out = nt;
+    *remap_out = remap;
+}
+
+namespace {
+
+template <int OP>
+int launch_csr_op(const DevCsr &A, const CsrArgs &a, bool finest, hipStream_t st, const KernelConfig &c)
+{
+    bool nt;
+    int remap;
+    csr_placement(A, c, &nt, &remap);
+    return finest ? launch_csr_tagged<OP, 1>(A, a, nt, remap, st, c) : launch_csr_tagged<OP, 0>(A, a, nt, remap, st, c);
 }
 
 // ------------------------------------------------------------------ elementwise
@@ -1458,18 +1489,16 @@ int build_rowblocks(int nrow, const int *rowptr, int *out)
     return nb;
 }
 
-KernelConfig &kernel_config() { return g_cfg; }
-
-int launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool finest, hipStream_t st)
+int launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool finest, hipStream_t st, const KernelConfig &cfg)
 {
     switch (op) {
-    case OP_SPMV: return launch_csr_op<OP_SPMV>(A, a, finest, st);
-    case OP_RESID: return launch_csr_op<OP_RESID>(A, a, finest, st);
-    case OP_JACOBI: return launch_csr_op<OP_JACOBI>(A, a, finest, st);
-    case OP_ADD: return launch_csr_op<OP_ADD>(A, a, finest, st);
-    case OP_SPMV_DOT: return launch_csr_op<OP_SPMV_DOT>(A, a, finest, st);
-    case OP_RESNORM: return launch_csr_op<OP_RESNORM>(A, a, finest, st);
-    case OP_JACOBI_DOT: return launch_csr_op<OP_JACOBI_DOT>(A, a, finest, st);
+    case OP_SPMV: return launch_csr_op<OP_SPMV>(A, a, finest, st, cfg);
+    case OP_RESID: return launch_csr_op<OP_RESID>(A, a, finest, st, cfg);
+    case OP_JACOBI: return launch_csr_op<OP_JACOBI>(A, a, finest, st, cfg);
+    case OP_ADD: return launch_csr_op<OP_ADD>(A, a, finest, st, cfg);
+    case OP_SPMV_DOT: return launch_csr_op<OP_SPMV_DOT>(A, a, finest, st, cfg);
+    case OP_RESNORM: return launch_csr_op<OP_RESNORM>(A, a, finest, st, cfg);
+    case OP_JACOBI_DOT: return launch_csr_op<OP_JACOBI_DOT>(A, a, finest, st, cfg);
     }
     return 0;
 }

@@ -70,7 +70,9 @@ struct DevCsr {
     int nint = 0, nbnd = 0;
 };
 
-// run-time choice of the SpMV-type kernel family (A/B measurements; defaults = the fastest measured)
+// per-handle choice of the SpMV-type kernel family (A/B measurements; defaults = the fastest measured).
+// Lives in the Engine (sparsh_set_kernel_config / sparsh_set_const_slots act on a handle): no
+// process-wide state.
 struct KernelConfig {
     int kind = 3;       // 0 workgroup CSR-stream, 1 wave CSR-stream, 2 sliced ELL, 3 sliced diagonals; 2 and 3 fall
                         // back (3 -> 2 -> 0) where the operator does not qualify for the mirror
@@ -81,7 +83,10 @@ struct KernelConfig {
     bool table = true;  // use the level-wide stencil table where a level has one
     bool const_slots = true;  // layout option read at setup: fold constant diagonals of a slice into one scalar
 };
-KernelConfig &kernel_config();
+
+// which kernel a launch of launch_csr on operator A runs under cfg (one decision, used by the
+// launcher and by every report of it)
+enum CsrFamily : int { FAM_CSR_BLOCK = 0, FAM_CSR_WAVE = 1, FAM_SELL = 2, FAM_SDIA = 3, FAM_SDIA_TAB = 4 };
 
 constexpr int kBlock = 256;       // threads per workgroup (4 waves)
 constexpr int kStreamNnz = 2048;  // products staged in LDS per workgroup (16 KiB)
@@ -123,7 +128,11 @@ int build_waveblocks(int nrow, const int *rowptr, int *out);
 
 // returns the number of per-workgroup partial sums the launch writes (reducing ops)
 // `finest`: launch on the finest level (selects a separately named kernel instance for profilers)
-int launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool finest, hipStream_t st);
+int launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool finest, hipStream_t st, const KernelConfig &cfg);
+CsrFamily csr_family(const DevCsr &A, const KernelConfig &cfg);
+const char *csr_family_name(CsrFamily f);
+// placement the launcher picks for A under cfg: non-temporal matrix stream, XCD remap mode
+void csr_placement(const DevCsr &A, const KernelConfig &cfg, bool *nt, int *remap);
 
 // x_i = omega*b_i/d_i : first Jacobi sweep from a zero guess (bitwise equal to the full sweep)
 void launch_jacobi_zero(int n, const double *b, const double *d, double omega, double *x, hipStream_t st);

@@ -40,9 +40,9 @@ def test_state_and_range_errors():
         A.setup(sa.default_params(print_setup=0, sweeps=0), host_only=True)
     assert e.value.code == sa.SPARSH_EINVAL
     with pytest.raises(sa.SparshError) as e:
-        sa.set_kernel_config(kind=7)
+        A.set_kernel_config(kind=7)
     assert e.value.code == sa.SPARSH_EINVAL
-    sa.set_kernel_config()
+    A.set_kernel_config()
 
 
 def test_singular_coarse_matrix_is_reported():
@@ -114,3 +114,24 @@ def test_matrix_market_reader(tmp_path):
     scipy.io.mmwrite(f, sp.tril(S), symmetry="symmetric")  # 1-based, lower triangle only
     rp2, ci2, v2 = problems.read_matrix_market(f)
     assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci) and np.array_equal(v2, v)
+
+
+def test_create_csr_validates_its_input():
+    """One O(nnz) pass at create time: a non-monotone rowptr or an out-of-range column must be refused
+    (SPARSH_EINVAL) instead of becoming an out-of-bounds access on the device."""
+    rp, ci, v = problems.poisson2d(12)
+    bad = ci.copy()
+    bad[17] = len(rp) - 1  # == ncol: one past the last column
+    with pytest.raises(sa.SparshError) as e:
+        sa.sp_matrix_mg(rp, bad, v)
+    assert e.value.code == sa.SPARSH_EINVAL and "colindex" in str(e.value)
+    bad[17] = -3
+    with pytest.raises(sa.SparshError) as e:
+        sa.sp_matrix_mg(rp, bad, v)
+    assert e.value.code == sa.SPARSH_EINVAL
+    rp2 = rp.copy()
+    rp2[5], rp2[6] = rp2[6], rp2[5] - 1  # decreasing
+    with pytest.raises(sa.SparshError) as e:
+        sa.sp_matrix_mg(rp2, ci, v)
+    assert e.value.code == sa.SPARSH_EINVAL and "rowptr" in str(e.value)
+    sa.sp_matrix_mg(rp, ci, v).close()  # the untouched arrays pass

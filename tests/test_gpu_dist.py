@@ -186,3 +186,55 @@ def test_comm_microbenchmarks_are_collective_and_harmless():
     A1 = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET))
     assert A1.bench_comm("halo", 0, 3) == -1.0   # single GPU: no such step
     A1.close()
+
+
+def test_transport_failure_is_reported_not_swallowed():
+    """A failed halo exchange must surface as SPARSH_ECOMM from the solver (and stay sticky on the
+    handle), not return SPARSH_OK with garbage.  The in-process transport fails on every rank from its
+    40th exchange on (fault-injection hook)."""
+    rp, ci, v = problems.poisson3d(30)
+    n = len(rp) - 1
+    G = 2
+    group = sa.comm_group_create(G)
+    res = [None] * G
+    errs = []
+    gate = threading.Barrier(G)
+
+    def work(r):
+        try:
+            A = sa.sp_matrix_mg(rp, ci, v)
+            A.comm_init_group(group, r)
+            A.setup(sa.default_params(**QUIET, replicate_rows=2000))
+            lo, hi, _ = A.local_range(0)
+            b = np.ones(hi - lo)
+            x = np.zeros(hi - lo)
+            h, rc = A.solve("pcg", b, x)          # healthy transport first
+            assert rc == 0
+            A.sync()
+            gate.wait(timeout=120)
+            if r == 0:
+                sa.comm_group_fail_after(group, 40)
+            gate.wait(timeout=120)
+            codes, msgs = [], []
+            for method in ("pcg", "amg"):
+                try:
+                    A.solve(method, b, np.zeros(hi - lo))
+                    codes.append(0)
+                except sa.SparshError as e:
+                    codes.append(e.code)
+                    msgs.append(str(e))
+            res[r] = (codes, msgs)
+            A.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in ts), "a virtual rank hung"
+    assert not errs, errs
+    sa.comm_group_destroy(group)
+    for codes, msg in res:
+        assert codes == [sa.SPARSH_ECOMM, sa.SPARSH_ECOMM], (codes, msg)   # second call: sticky

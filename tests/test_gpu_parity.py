@@ -79,7 +79,7 @@ def test_kernel_families_bitwise(case, kind, vec):
     rng = np.random.default_rng(17)
     try:
         for nt, remap in ((1, 1), (0, 0), (1, 16), (-1, -1)):
-            sa.set_kernel_config(kind=kind, vec=vec, nt=nt, remap=remap)
+            A.set_kernel_config(kind=kind, vec=vec, nt=nt, remap=remap)
             for l in range(A.nlevels):
                 n = A.level_info(l)["nrow"]
                 x = rng.standard_normal(n)
@@ -104,7 +104,7 @@ def test_kernel_families_bitwise(case, kind, vec):
         _hist_ok(h, ho)
         assert np.linalg.norm(xx - xo) <= 1e-8 * np.linalg.norm(xo)
     finally:
-        sa.set_kernel_config()
+        A.set_kernel_config()
 
 
 def test_blas1(case):
@@ -342,11 +342,7 @@ def test_constant_slot_folding_bitwise():
     for name, (rp, ci, v) in (("p3d", (rp3, ci3, v3)), ("p3d_perturbed", (rp3, ci3, v3p)), ("mixed", _mixed_coefficients(300))):
         n = len(rp) - 1
         A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET, max_levels=2))
-        try:
-            sa.set_const_slots(False)
-            B = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET, max_levels=2))
-        finally:
-            sa.set_const_slots(True)
+        B = sa.sp_matrix_mg(rp, ci, v).set_const_slots(False).setup(sa.default_params(**QUIET, max_levels=2))  # per handle
         assert A.level_format(0)[0] == 3 and B.level_format(0)[0] == 3
         sl, vb, _ = A.level_layout(0)
         slb, vbb, _ = B.level_layout(0)
@@ -361,7 +357,8 @@ def test_constant_slot_folding_bitwise():
         x = rng.standard_normal(n)
         b = rng.standard_normal(n)
         for nt, remap in ((1, 16), (0, 1), (-1, -1)):
-            sa.set_kernel_config(kind=3, vec=0, nt=nt, remap=remap)
+            A.set_kernel_config(kind=3, vec=0, nt=nt, remap=remap)
+            B.set_kernel_config(kind=3, vec=0, nt=nt, remap=remap)
             try:
                 ya, yb = A.op_spmv(0, x), B.op_spmv(0, x)
                 assert np.array_equal(ya, yb) and np.array_equal(ya, oracle.spmv(O, x)), name
@@ -371,7 +368,8 @@ def test_constant_slot_folding_bitwise():
                 ra, rb = A.op_resnorm(0, b, x), B.op_resnorm(0, b, x)
                 assert abs(ra - rb) <= 1e-13 * ra and abs(ra - oracle.residual(O, b, x)) <= 1e-12 * ra
             finally:
-                sa.set_kernel_config()
+                A.set_kernel_config()
+                B.set_kernel_config()
         A.close()
         B.close()
 

@@ -28,22 +28,23 @@ def main():
     ap.add_argument("--no-const", action="store_true", help="build the sliced-diagonal layout without constant-slot folding")
     ap.add_argument("--kinds", type=int, nargs="*", default=[3, 2], help="kernel families of the --remaps sweep")
     a = ap.parse_args()
-    if a.no_const:
-        sa.set_const_slots(False)
     if a.fem:
         rp, ci, v = problems.fem_unstructured(a.fem, ordering=a.ordering)
     else:
         rp, ci, v = problems.poisson3d(a.n) if a.dim == 3 else problems.poisson2d(a.n)
-    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, print_solve=0))
+    A = sa.sp_matrix_mg(rp, ci, v)
+    if a.no_const:
+        A.set_const_slots(False)
+    A.setup(sa.default_params(print_setup=0, print_solve=0))
     if a.cfg:
-        sa.set_kernel_config(*a.cfg)
+        A.set_kernel_config(*a.cfg)
     if a.remaps:
         print(f"{'config':28s} {'op':8s} {'lvl':>3s} {'us':>9s} {'GB/s':>8s} {'frac8T':>7s}")
         for rnd in range(a.rounds):
             for (k, v) in [(kk, 0) for kk in a.kinds]:
                 for nt in (1, 0):
                     for rm in a.remaps:
-                        sa.set_kernel_config(kind=k, vec=v, nt=nt, remap=rm)
+                        A.set_kernel_config(kind=k, vec=v, nt=nt, remap=rm)
                         for l in a.vlevels:
                             if l >= A.nlevels:
                                 continue
@@ -52,14 +53,14 @@ def main():
                             sec = A.bench_op("jacobi", l, a.reps)
                             gbs = (12 * nnz + 36 * n) / sec / 1e9
                             print(f"kind={k} vec={v} nt={nt} remap={rm:<5d} r{rnd:<2d} jacobi   {l:3d} {sec * 1e6:9.1f} {gbs:8.1f} {gbs / 8000:7.3f}", flush=True)
-        sa.set_kernel_config()
+        A.set_kernel_config()
         return
     if a.variants:
         print(f"{'config':28s} {'op':8s} {'lvl':>3s} {'us':>9s} {'GB/s':>8s} {'frac8T':>7s}")
         cfgs = [(k, v, nt, rm) for k in (0, 1, 2, 3) for v in ((0, 1) if k < 2 else (0,)) for nt in (1, 0) for rm in (1, 16)]
         for rnd in range(a.rounds):
             for (k, v, nt, rm) in cfgs:
-                sa.set_kernel_config(kind=k, vec=v, nt=nt, remap=rm)
+                A.set_kernel_config(kind=k, vec=v, nt=nt, remap=rm)
                 for l in a.vlevels:
                     if l >= A.nlevels:
                         continue
@@ -69,7 +70,7 @@ def main():
                         sec = A.bench_op(op, l, a.reps)
                         gbs = nbytes / sec / 1e9
                         print(f"kind={k} vec={v} nt={nt} remap={rm} r{rnd:<3d} {op:8s} {l:3d} {sec * 1e6:9.1f} {gbs:8.1f} {gbs / 8000:7.3f}", flush=True)
-        sa.set_kernel_config()
+        A.set_kernel_config()
         return
     print("level formats (3 sliced diagonals, 2 sliced ELL, 0 CSR-stream):", [A.level_format(l)[0] for l in range(A.nlevels)])
     print("sliced-diagonal slots / value blocks per level:", [A.level_layout(l) for l in range(A.nlevels)])

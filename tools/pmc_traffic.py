@@ -25,22 +25,27 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 N_GRID = 216
 
 
-def run():
+def run(grid=N_GRID, cfg=None, no_fold=False, layout_out=None):
     import sparsh_amg_amd as sa
     from sparsh_amg_amd import problems
 
-    rp, ci, v = problems.poisson3d(N_GRID)
-    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, print_solve=0))
-    cfg = os.environ.get("SPARSH_PMC_CFG")  # "kind,vec,nt,remap": override the per-operator policy (diagnostics)
+    rp, ci, v = problems.poisson3d(grid)
+    A = sa.sp_matrix_mg(rp, ci, v)
+    if no_fold:
+        A.set_const_slots(False)
+    A.setup(sa.default_params(print_setup=0, print_solve=0))
+    cfg = cfg or os.environ.get("SPARSH_PMC_CFG")  # "kind,vec,nt,remap": override the per-operator policy (diagnostics)
     if cfg:
-        sa.set_kernel_config(*[int(t) for t in cfg.split(",")])
+        A.set_kernel_config(*[int(t) for t in cfg.split(",")])
     for op in ("axpby", "dot", "copy_int", "jacobi"):
         A.bench_op(op, 0, 4)
     slots, vblocks, meta = A.level_layout(0)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(root, "gpurun_out", "pmc_layout.json"), "w") as f:
-        json.dump({"slots": slots, "value_blocks": vblocks, "descriptor_bytes": meta}, f)
+    if layout_out is None:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        layout_out = os.path.join(root, "gpurun_out", "pmc_layout.json")
+    with open(layout_out, "w") as f:
+        json.dump({"slots": slots, "value_blocks": vblocks, "descriptor_bytes": meta, "kernel": A.level_kernel(0), "grid": grid}, f)
 
 
 def collect(d):
@@ -64,9 +69,9 @@ def collect(d):
     return {k: sum(v) / len(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
 
 
-def summarize(fetch_dir, write_dir, out_path):
-    n = N_GRID ** 3
-    nnz = 7 * n - 6 * N_GRID ** 2
+def summarize(fetch_dir, write_dir, out_path, grid=N_GRID, layout_path=None, quiet=False):
+    n = grid ** 3
+    nnz = 7 * n - 6 * grid ** 2
     fetch, cnt = collect(fetch_dir)
     write, _ = collect(write_dir)
     known_read = {"axpby": 16 * n, "dot": 16 * n, "copy_int": 4 * n}
@@ -81,11 +86,11 @@ def summarize(fetch_dir, write_dir, out_path):
     # the 8-byte streams).  raw = bytes4/f4 + bytes8/f8  ->  solve for bytes8.
     pad_nnz = 7 * n
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lay_path = os.path.join(root, "gpurun_out", "pmc_layout.json")
+    lay_path = layout_path or os.path.join(root, "gpurun_out", "pmc_layout.json")
     layout = json.load(open(lay_path)) if os.path.exists(lay_path) else None
     kind = int(fetch.pop("_kind", 2.0))
     cnt.pop("_kind", None)
-    bytes4 = (4 * pad_nnz + 4 * n) if kind == 2 else 0
+    bytes4 = (4 * pad_nnz + 4 * n) if kind == 2 else ((4 * nnz + 4 * n) if kind == 0 else 0)
     bytes8 = (fetch["jacobi"] - bytes4 / f4) * f8
     read_total = bytes4 + bytes8
     # bytes of the value stream: sliced diagonals store 64-value blocks only for non-constant slots
@@ -110,9 +115,12 @@ def summarize(fetch_dir, write_dir, out_path):
         "layout": layout,
         "x_vector_fetches_per_entry": (bytes8 - val_bytes - meta_bytes - 8 * n) / (8 * n),
     }
-    with open(out_path, "w") as f:
-        json.dump(res, f, indent=1)
-    print(json.dumps(res, indent=1))
+    if out_path:
+        with open(out_path, "w") as f:
+            json.dump(res, f, indent=1)
+    if not quiet:
+        print(json.dumps(res, indent=1))
+    return res
 
 
 if __name__ == "__main__":
@@ -120,8 +128,12 @@ if __name__ == "__main__":
     ap.add_argument("--run", action="store_true")
     ap.add_argument("--summarize", nargs=2)
     ap.add_argument("--out", default="profiles/pmc_latest.json")
+    ap.add_argument("--grid", type=int, default=N_GRID)
+    ap.add_argument("--kcfg", default=None, help="kind,vec,nt,remap")
+    ap.add_argument("--no-fold", action="store_true")
+    ap.add_argument("--layout", default=None, help="where --run writes / --summarize reads the layout description")
     a = ap.parse_args()
     if a.run:
-        run()
+        run(a.grid, a.kcfg, a.no_fold, a.layout)
     elif a.summarize:
-        summarize(a.summarize[0], a.summarize[1], a.out)
+        summarize(a.summarize[0], a.summarize[1], a.out, a.grid, a.layout)
