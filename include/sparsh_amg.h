@@ -68,7 +68,8 @@ typedef struct sparsh_params {
                            rank (no halo exchange below that size)            [SPARSH_REPLICATE_ROWS] */
     int precond_fp32;   /* 0 (default): everything fp64, bitwise parity with the reference's arithmetic.
                            1: SPARSH_PCG / SPARSH_PBICG run their V-cycle on a float copy of the hierarchy (float values
-                           and vectors; needs the sliced-diagonal layout on every level, one GPU) while
+                           and vectors: the sliced-diagonal value blocks where a level has that layout, the
+                           CSR values otherwise; one GPU) while
                            the CG recurrences, residuals and the stopping test stay fp64.  Not a parity
                            mode: a different (cheaper) preconditioner, same solution to tol.
                                                                                [SPARSH_PRECOND_FP32] */
@@ -130,6 +131,13 @@ int sparsh_level_format(sparsh_handle h, int level, int *kind, long *stored_entr
  * handle (A/B measurements; default on). */
 int sparsh_level_layout(sparsh_handle h, int level, long *slots, long *value_blocks, long *meta_bytes);
 int sparsh_set_const_slots(sparsh_handle h, int enable);
+/* Table levels of grid stencils (offsets -1, 0, +1, +-line[, +-plane]) run, on whole-level launches, a
+ * variant that stages x[r0 - line, r0 + T + line) of every workgroup's T rows in LDS, so the centre, +-1 and
+ * +-line neighbours come out of LDS and only the +-plane neighbours are gathered from L2 (bitwise the same
+ * results).  sparsh_set_tile(h, 0) switches it off for the handle (A/B measurements; default on);
+ * sparsh_level_tile_rows reports T for a level (0: the variant is not used there). */
+int sparsh_set_tile(sparsh_handle h, int enable);
+int sparsh_level_tile_rows(sparsh_handle h, int level, int *rows);
 /* Multi-GPU diagnostics (collective: every rank calls it with the same arguments): average seconds
  * of one communication step alone, timed with HIP events on the engine's stream.  what = 0: halo
  * exchange of level `level`'s operator; 1: the 16-byte all-reduce of the fused scalars; 2: the
@@ -207,6 +215,9 @@ int sparsh_op_resnorm(sparsh_handle h, int level, const double *b, const double 
 int sparsh_op_restrict(sparsh_handle h, int level, const double *r, double *bc);
 int sparsh_op_prolong(sparsh_handle h, int level, const double *xc, double *xf);
 int sparsh_op_coarse(sparsh_handle h, const double *b, double *x);
+/* z = V32(r): one application of the opt-in fp32 preconditioner (params.precond_fp32 = 1): a V(nu,nu) cycle from a
+ * zero guess on the float copy of the hierarchy, fp64 in/out.  Checked against oracle_vcycle_f32. */
+int sparsh_op_precond_f32(sparsh_handle h, const double *r, double *z);
 int sparsh_op_dot(sparsh_handle h, int n, const double *x, const double *y, double *out);
 int sparsh_op_nrm2(sparsh_handle h, int n, const double *x, double *out);
 int sparsh_op_axpby(sparsh_handle h, int n, double a, const double *x, double bcoef, double *y);

@@ -111,6 +111,7 @@ def lib():
         fn = getattr(L, name)
         fn.restype = C.c_int
         fn.argtypes = [P(OCsr), c_dbl_p, c_dbl_p, P(OParams), c_dbl_p, C.c_int]
+    L.oracle_vcycle_f32.argtypes = [C.c_void_p, c_dbl_p, c_dbl_p]
     L.oracle_time_spmv.restype = C.c_double
     L.oracle_time_spmv.argtypes = [P(OCsr), c_dbl_p, c_dbl_p, C.c_int, C.c_int]
     L.oracle_stream_triad.restype = C.c_double
@@ -304,6 +305,13 @@ class Hierarchy:
         hist = np.zeros(hist_cap)
         c = lib().oracle_amg_solve(self.ptr, _dp(b), _dp(x), iterations, _dp(hist), hist_cap)
         return x, hist[: min(c, hist_cap)].copy()
+
+    def vcycle_f32(self, r):
+        """z = V32(r): the float restatement of one V-cycle from a zero guess (fp32-preconditioner checker)."""
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        z = np.empty_like(r)
+        lib().oracle_vcycle_f32(self.ptr, _dp(r), _dp(z))
+        return z
 
     def pcg(self, b, x0=None, max_it=1 << 30, hist_cap=4096):
         b = np.ascontiguousarray(b, dtype=np.float64)

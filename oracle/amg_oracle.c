@@ -843,6 +843,93 @@ static void vcycle(oamg *S)
     }
 }
 
+/* ---- float restatement of the V-cycle (checker of the product's OPT-IN fp32 preconditioner; the
+ * reference has no such mode: SURVEY section 8f-4 "mixed precision").  Same order of operations as
+ * vcycle() above (src/AMG_phases.cpp:198-216, src/AMG_smoothers.cpp:62-72), every operand and every
+ * intermediate rounded to float: values (float)a_ij, (float)omega, vectors float, zero initial guess on
+ * every level (first sweep x = omega*b/d), row sums in stored order, restriction as the gather over
+ * P^T in ascending fine-row order.  The coarsest solve is done in double and rounded (the product applies
+ * a float inverse or its fp64 block factors: agreement to float accuracy times the coarse condition number). */
+static void spmv_f32(const ocsr *A, const float *x, float *y)
+{
+    const int *rp = A->rowptr, *ci = A->col;
+    const double *v = A->val;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < A->nrow; i++) {
+        float sum = 0.f;
+        for (int j = rp[i]; j < rp[i + 1]; j++) sum += (float)v[j] * x[ci[j]];
+        y[i] = sum;
+    }
+}
+
+/* z = V32(r): one V(nu,nu) cycle in float from a zero guess; sweeps = smooth_iter + 1 */
+void oracle_vcycle_f32(oamg *S, const double *r, double *z)
+{
+    const int l = S->l;
+    const int nu = S->prm.smooth_iter + 1;
+    const float w = (float)S->prm.omega;
+    oracle_set_threads(S->prm.threads);
+    float **X = (float **)calloc((size_t)l + 1, sizeof(float *));
+    float **B = (float **)calloc((size_t)l + 1, sizeof(float *));
+    ocsr **Rt = (ocsr **)calloc((size_t)l + 1, sizeof(ocsr *));
+    int nmax = 0;
+    for (int k = 0; k <= l; k++) {
+        const int n = S->A[k]->nrow;
+        X[k] = (float *)calloc((size_t)n, sizeof(float));
+        B[k] = (float *)calloc((size_t)n, sizeof(float));
+        if (n > nmax) nmax = n;
+        if (k < l) Rt[k] = oracle_transpose(S->P[k]);
+    }
+    float *h = (float *)calloc((size_t)nmax, sizeof(float));
+    for (int i = 0; i < S->A[0]->nrow; i++) B[0][i] = (float)r[i];
+    for (int k = 0; k < l; k++) {
+        const ocsr *A = S->A[k];
+        const int n = A->nrow;
+        float *x = X[k], *b = B[k];
+        for (int i = 0; i < n; i++) x[i] = w * b[i] / (float)A->diag[i]; /* first sweep from x = 0 */
+        for (int sw = 1; sw < nu; sw++) {
+            spmv_f32(A, x, h);
+            for (int i = 0; i < n; i++) x[i] = x[i] + w * (b[i] - h[i]) / (float)A->diag[i];
+        }
+        spmv_f32(A, x, h);
+        for (int i = 0; i < n; i++) h[i] = b[i] - h[i];
+        spmv_f32(Rt[k], h, B[k + 1]); /* b_c = P^T r, gathered in ascending fine-row order */
+    }
+    {
+        const int n = S->A[l]->nrow;
+        double *bd = (double *)calloc((size_t)n, sizeof(double)), *xd = (double *)calloc((size_t)n, sizeof(double));
+        for (int i = 0; i < n; i++) bd[i] = (double)B[l][i];
+        oracle_coarse_solve(S, bd, xd);
+        for (int i = 0; i < n; i++) X[l][i] = (float)xd[i];
+        free(bd);
+        free(xd);
+    }
+    for (int k = l; k > 0; k--) {
+        const ocsr *A = S->A[k - 1], *P = S->P[k - 1];
+        const int n = A->nrow;
+        float *x = X[k - 1], *b = B[k - 1];
+        for (int i = 0; i < n; i++) {
+            float sum = 0.f;
+            for (int j = P->rowptr[i]; j < P->rowptr[i + 1]; j++) sum += (float)P->val[j] * X[k][P->col[j]];
+            x[i] = sum + x[i];
+        }
+        for (int sw = 0; sw < nu; sw++) {
+            spmv_f32(A, x, h);
+            for (int i = 0; i < n; i++) x[i] = x[i] + w * (b[i] - h[i]) / (float)A->diag[i];
+        }
+    }
+    for (int i = 0; i < S->A[0]->nrow; i++) z[i] = (double)X[0][i];
+    for (int k = 0; k <= l; k++) {
+        free(X[k]);
+        free(B[k]);
+        if (Rt[k]) oracle_csr_free(Rt[k]);
+    }
+    free(X);
+    free(B);
+    free(Rt);
+    free(h);
+}
+
 /* AMG_solver::AMG_solve_jacobi (src/AMG_phases.cpp:151-230).
  * iterations > 0: exactly that many V-cycles; iterations == -1: until ||Ax-b|| <= tol. */
 int oracle_amg_solve(oamg *S, const double *b, double *x, int iterations, double *hist, int hist_cap)

@@ -97,6 +97,10 @@ int oracle_solver_pbicg(ocsr *A, const double *b, double *x, const oparams *prm,
  * at most max_it iterations). Returns iterations done; *seconds = solve-loop time. */
 int oracle_pcg_presetup(oamg *S, const double *b, double *x, int max_it, double *hist, int hist_cap, double *seconds);
 
+/* float restatement of one V(nu,nu) cycle from a zero guess, z = V32(r): checker of the product's opt-in
+ * fp32 preconditioner mode (not a reference feature) */
+void oracle_vcycle_f32(oamg *S, const double *r, double *z);
+
 /* ---- cpu_baseline helpers of bench.py (timing only) ----
  * oracle_time_spmv: average seconds of one y = A x (the reference's mkl_sparse_d_mv call,
  * src/AMG_cycle_utilities.cpp:87) over `reps` repetitions after one warm-up, `threads` OpenMP threads.

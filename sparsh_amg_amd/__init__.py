@@ -86,12 +86,15 @@ def _load():
         "sparsh_level_format": (C.c_int, [H, C.c_int, c_int_p, C.POINTER(C.c_long)]),
         "sparsh_level_layout": (C.c_int, [H, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
         "sparsh_set_const_slots": (C.c_int, [H, C.c_int]),
+        "sparsh_set_tile": (C.c_int, [H, C.c_int]),
+        "sparsh_level_tile_rows": (C.c_int, [H, C.c_int, c_int_p]),
         "sparsh_bench_comm": (C.c_int, [H, C.c_int, C.c_int, C.c_int, c_dbl_p]),
         "sparsh_level_kernel": (C.c_char_p, [H, C.c_int]),
         "sparsh_num_levels": (C.c_int, [H]),
         "sparsh_level_info": (C.c_int, [H, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p]),
         "sparsh_level_csr": (C.c_int, [H, C.c_int, C.c_int, c_int_p, c_int_p, c_dbl_p]),
         "sparsh_coarse_inverse": (C.c_int, [H, c_dbl_p]),
+        "sparsh_op_precond_f32": (C.c_int, [H, c_dbl_p, c_dbl_p]),
         "sparsh_coarse_info": (C.c_int, [H, c_int_p, C.POINTER(C.c_long)]),
         "sparsh_setup_seconds": (C.c_double, [H]),
         "sparsh_vcycle": (C.c_int, [H, c_dbl_p, c_dbl_p, C.c_int, c_dbl_p, C.c_int, c_int_p]),
@@ -239,7 +242,17 @@ class sp_matrix_mg:
         _check(lib.sparsh_set_const_slots(self._h, int(bool(enable))))
         return self
 
-    def set_kernel_config(self, kind=3, vec=True, nt=-1, remap=-1):
+    def set_tile(self, enable=True):
+        """LDS-tiled variant of the table kernel on whole-level launches of grid stencils (default on)."""
+        _check(lib.sparsh_set_tile(self._h, int(bool(enable))))
+        return self
+
+    def level_tile_rows(self, level):
+        r = C.c_int(0)
+        _check(lib.sparsh_level_tile_rows(self._h, level, C.byref(r)))
+        return r.value
+
+    def set_kernel_config(self, kind=3, vec=1, nt=-1, remap=-1):
         """Select the SpMV-type kernel family of this handle; see sparsh_set_kernel_config."""
         _check(lib.sparsh_set_kernel_config(self._h, int(kind), int(vec), int(nt), int(remap)))
         return self
@@ -491,6 +504,13 @@ class sp_matrix_mg:
         x = np.zeros_like(b)
         _check(lib.sparsh_op_coarse(self._h, _dp(b), _dp(x)))
         return x
+
+    def op_precond_f32(self, r):
+        """z = V32(r): one application of the opt-in fp32 preconditioner (needs precond_fp32=1)."""
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        z = np.zeros_like(r)
+        _check(lib.sparsh_op_precond_f32(self._h, _dp(r), _dp(z)))
+        return z
 
     def op_dot(self, x, y):
         x = np.ascontiguousarray(x, dtype=np.float64)

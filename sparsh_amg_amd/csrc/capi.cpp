@@ -196,7 +196,7 @@ int sparsh_set_kernel_config(sparsh_handle h, int kind, int vec, int nt, int rem
     if (kind < 0 || kind > 3) return fail(SPARSH_EINVAL, "kind must be 0 (workgroup CSR-stream), 1 (wave CSR-stream), 2 (sliced ELL) or 3 (sliced diagonals)");
     KernelConfig &c = h->eng->kernel_cfg();
     c.kind = kind;
-    c.vec = vec != 0;
+    c.vec = vec != 0 ? 1 : 0;
     c.nt = nt > 0;
     c.remap = remap < 0 ? 0 : remap;
     c.auto_policy = (nt < 0 || remap < 0);
@@ -274,6 +274,21 @@ int sparsh_bench_comm(sparsh_handle h, int what, int level, int reps, double *av
     REQUIRE_READY(h);
     if (!avg_seconds) return fail(SPARSH_EINVAL, "null output");
     *avg_seconds = h->eng->bench_comm(what, level, reps);
+    return SPARSH_OK;
+}
+
+int sparsh_set_tile(sparsh_handle h, int enable)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    h->eng->kernel_cfg().tile = enable != 0;
+    return SPARSH_OK;
+}
+
+int sparsh_level_tile_rows(sparsh_handle h, int level, int *rows)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    if (rows) *rows = csr_family(h->eng->level(level).A, h->eng->kernel_cfg()) == FAM_SDIA_TAB ? sdia_tile_rows(h->eng->level(level).A, h->eng->kernel_cfg()) : 0;
     return SPARSH_OK;
 }
 
@@ -623,6 +638,17 @@ int sparsh_op_coarse(sparsh_handle h, const double *b, double *x)
     DBuf db(E, n, b), dx(E, n);
     E.op_coarse(db.p, dx.p);
     return done(E, dx.get(x));
+}
+
+int sparsh_op_precond_f32(sparsh_handle h, const double *r, double *z)
+{
+    REQUIRE_READY(h);
+    REQUIRE_SINGLE(h);
+    Engine &E = *h->eng;
+    const size_t n = (size_t)E.level(0).n;
+    DBuf dr(E, n, r), dz(E, n);
+    if (!E.op_precond_f32(dr.p, dz.p)) return fail(SPARSH_ESTATE, E.error);
+    return done(E, dz.get(z));
 }
 
 int sparsh_op_dot(sparsh_handle h, int n, const double *x, const double *y, double *out)

@@ -90,6 +90,7 @@ void CoarseSolver::release()
     inv_ = sinv_ = z_ = nullptr;
     perm_ = nullptr;
     out_ = in_ = BtDevCsr();
+    out_ell_ = in_ell_ = BtDevEll();
     steps_.clear();
     n_ = 0;
 }
@@ -117,6 +118,31 @@ T *dev_upload(std::vector<void *> &allocs, const T *src, size_t count, std::stri
         return nullptr;
     }
     return d;
+}
+
+// ELL copy of a coupling piece for the solve kernel (at most 8 entries per row, else the CSR form is used)
+bool upload_ell(std::vector<void *> &allocs, const HostCsr &M, BtDevEll &E, std::string &err)
+{
+    const int n = M.nrow;
+    int k = 0;
+    for (int i = 0; i < n; ++i) k = std::max(k, M.rowptr[i + 1] - M.rowptr[i]);
+    E = BtDevEll();
+    if (k == 0 || k > 8) return true;
+    std::vector<int> ci((size_t)k * n);
+    std::vector<double> v((size_t)k * n, 0.0);
+    for (int i = 0; i < n; ++i) {
+        int q = 0;
+        for (int j = M.rowptr[i]; j < M.rowptr[i + 1]; ++j, ++q) {
+            ci[(size_t)q * n + i] = M.col[j];
+            v[(size_t)q * n + i] = M.val[j];
+        }
+        for (; q < k; ++q) ci[(size_t)q * n + i] = i;
+    }
+    E.ci = dev_upload(allocs, ci.data(), ci.size(), err);
+    E.v = dev_upload(allocs, v.data(), v.size(), err);
+    if (!E.ci || !E.v) return false;
+    E.k = k;
+    return true;
 }
 
 bool upload_piece(std::vector<void *> &allocs, const HostCsr &M, BtDevCsr &D, std::string &err)
@@ -159,7 +185,7 @@ bool CoarseSolver::setup_bt(const HostCsr &A, hipStream_t st, std::string &err, 
         tmp.clear();
     };
     bool ok = upload_piece(allocs_, P.out, out_, err) && upload_piece(allocs_, P.in, in_, err) && upload_piece(tmp, P.diag, diag, err) &&
-              upload_piece(tmp, P.inT, inT, err);
+              upload_piece(tmp, P.inT, inT, err) && upload_ell(allocs_, P.out, out_ell_, err) && upload_ell(allocs_, P.in, in_ell_, err);
     perm_ = ok ? dev_upload(allocs_, P.perm.data(), (size_t)n, err) : nullptr;
     z_ = ok ? dev_alloc<double>(allocs_, (size_t)n, err) : nullptr;
     sinv_ = ok ? dev_alloc<double>(allocs_, (size_t)nb * B * B, err) : nullptr;
@@ -252,7 +278,8 @@ void CoarseSolver::solve(const double *b, double *x, hipStream_t st) const
     }
     const size_t bstride = (size_t)plan_.B * plan_.B;
     for (const Step &s : steps_)
-        bt_launch_solve_step(s.r0, s.bs, s.blk, s.nblk, s.mode, s.final_, plan_.B, bstride, sinv_, perm_, s.mode == 0 ? out_ : in_, b, z_, x, st);
+        bt_launch_solve_step(s.r0, s.bs, s.blk, s.nblk, s.mode, s.final_, plan_.B, bstride, sinv_, perm_, s.mode == 0 ? out_ : in_,
+                             s.mode == 0 ? out_ell_ : in_ell_, n_, b, z_, x, st);
 }
 
 }  // namespace sparsh

@@ -24,6 +24,13 @@ struct BtDevCsr {
     double *v = nullptr;
 };
 
+// ELL form of a coupling piece: entry k of row g at [k*n + g]; k = 0 when the piece is too ragged for it
+struct BtDevEll {
+    int k = 0;
+    int *ci = nullptr;
+    double *v = nullptr;
+};
+
 // Host plan of the block-tridiagonal factorisation (no device needed; inspected by tests).
 struct BtPlan {
     int n = 0, bw = 0, B = 0, nb = 0, mid = 0;
@@ -75,6 +82,7 @@ private:
     double *sinv_ = nullptr, *z_ = nullptr;
     int *perm_ = nullptr;
     BtDevCsr out_, in_;
+    BtDevEll out_ell_, in_ell_;
     std::vector<void *> allocs_;
     struct Step {
         int r0[2], bs[2], blk[2], nblk, mode, final_;
@@ -89,7 +97,8 @@ void bt_launch_schur(int r0, int bs, int o0, int obs, int ld, const BtDevCsr &ou
 void bt_launch_invert(int bs, int ld, double *S, double *S2, double *col0, double *col1, int *pivots, int *colmap, int *singular,
                       double *out, hipStream_t st);
 void bt_launch_solve_step(const int r0[2], const int bs[2], const int blk[2], int nblk, int mode, int final_, int ld, size_t blk_stride,
-                          const double *sinv, const int *perm, const BtDevCsr &A, const double *b, double *z, double *x, hipStream_t st);
+                          const double *sinv, const int *perm, const BtDevCsr &A, const BtDevEll &E, int n, const double *b, double *z, double *x,
+                          hipStream_t st);
 void launch_cvt_f2d(int n, const float *in, double *out, hipStream_t st);
 
 }  // namespace sparsh

@@ -217,42 +217,72 @@ struct BtStep {
 __global__ __launch_bounds__(kCB) void bt_solve_kernel(BtStep s, int mode, int final_, int ld, size_t blk_stride,
                                                        const double *__restrict__ sinv, const int *__restrict__ perm,
                                                        const int *__restrict__ a_rp, const int *__restrict__ a_ci,
-                                                       const double *__restrict__ a_v, const double *__restrict__ b,
-                                                       double *__restrict__ z, double *__restrict__ x)
+                                                       const double *__restrict__ a_v, int ell_k, int n,
+                                                       const int *__restrict__ e_ci, const double *__restrict__ e_v,
+                                                       const double *__restrict__ b, double *__restrict__ z, double *__restrict__ x)
 {
     extern __shared__ double w[];
     const int which = blockIdx.y;
     const int r0 = s.r0[which], bs = s.bs[which];
     const int row0 = blockIdx.x * kSolveRows;
     if (row0 >= bs) return;  // the second block of a step may be the shorter last block
-    for (int r = threadIdx.x; r < bs; r += kCB) {
-        const int g = r0 + r;
-        double acc = 0.0;
-        for (int j = a_rp[g]; j < a_rp[g + 1]; ++j) acc += a_v[j] * z[a_ci[j]];
-        w[r] = mode == 0 ? b[perm[g]] - acc : acc;
-    }
-    __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const double *__restrict__ M = sinv + (size_t)s.blk[which] * blk_stride;
     const int ra = row0 + 2 * wv, rb = ra + 1;
-    if (ra >= bs) return;
-    const bool hb = rb < bs;
-    const double *__restrict__ ma = M + (size_t)ra * ld;
-    const double *__restrict__ mb = M + (size_t)(hb ? rb : ra) * ld;
+    const bool ha = ra < bs, hb = rb < bs;
+    const double *__restrict__ ma = M + (size_t)(ha ? ra : 0) * ld;
+    const double *__restrict__ mb = M + (size_t)(hb ? rb : (ha ? ra : 0)) * ld;
+    // The rows of S^-1 do not depend on w: request the first 1024 columns of both rows now (16-byte
+    // loads, all in flight), so their HBM latency passes while w is assembled.  ld is a multiple of 64
+    // and rows are zero-padded, so pairs stay aligned and in bounds.
+    constexpr int U = 8;  // 8 x 128 columns
+    double2 va[U], vb[U];
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = c0 + lane * 2 + u * 128;
+            const bool ok = j < bs;
+            va[u] = ok ? *reinterpret_cast<const double2 *>(ma + j) : double2{0.0, 0.0};
+            vb[u] = ok ? *reinterpret_cast<const double2 *>(mb + j) : double2{0.0, 0.0};
+        }
+    };
+    load_chunk(0);
+    if (ell_k > 0) {
+        // ELL form of the coupling piece (entry k of row g at [k*n + g]; padding: value 0 on the row's own
+        // index): index/value loads do not wait for a row pointer, so the chain in front of w is two loads deep
+        for (int r = threadIdx.x; r < bs; r += kCB) {
+            const int g = r0 + r;
+            const double bg = mode == 0 ? b[perm[g]] : 0.0;
+            double acc = 0.0;
+#pragma unroll 4
+            for (int k = 0; k < ell_k; ++k) acc += e_v[(size_t)k * n + g] * z[e_ci[(size_t)k * n + g]];
+            w[r] = mode == 0 ? bg - acc : acc;
+        }
+    } else {
+        for (int r = threadIdx.x; r < bs; r += kCB) {
+            const int g = r0 + r;
+            double acc = 0.0;
+            for (int j = a_rp[g]; j < a_rp[g + 1]; ++j) acc += a_v[j] * z[a_ci[j]];
+            w[r] = mode == 0 ? b[perm[g]] - acc : acc;
+        }
+    }
+    __syncthreads();
     double sa = 0.0, sb = 0.0;
-    // ld is a multiple of 64 and rows are padded with zeros, so the 16-byte loads stay aligned / in bounds
-    for (int j = lane * 2; j < bs; j += 128) {
-        const double2 va = *reinterpret_cast<const double2 *>(ma + j);
-        const double2 vb = *reinterpret_cast<const double2 *>(mb + j);
-        const double w0 = w[j], w1 = (j + 1 < bs) ? w[j + 1] : 0.0;
-        sa += va.x * w0;
-        sa += va.y * w1;
-        sb += vb.x * w0;
-        sb += vb.y * w1;
+    for (int c0 = 0; c0 < bs; c0 += U * 128) {
+        if (c0 > 0) load_chunk(c0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = c0 + lane * 2 + u * 128;
+            const double w0 = j < bs ? w[j] : 0.0, w1 = j + 1 < bs ? w[j + 1] : 0.0;
+            sa += va[u].x * w0;
+            sa += va[u].y * w1;
+            sb += vb[u].x * w0;
+            sb += vb[u].y * w1;
+        }
     }
     sa = wsum(sa);
     sb = wsum(sb);
-    if (lane == 0) {
+    if (lane == 0 && ha) {
         const int ga = r0 + ra;
         const double za = mode == 0 ? sa : z[ga] - sa;
         z[ga] = za;
@@ -306,7 +336,8 @@ void bt_launch_invert(int bs, int ld, double *S, double *S2, double *col0, doubl
 }
 
 void bt_launch_solve_step(const int r0[2], const int bs[2], const int blk[2], int nblk, int mode, int final_, int ld, size_t blk_stride,
-                          const double *sinv, const int *perm, const BtDevCsr &A, const double *b, double *z, double *x, hipStream_t st)
+                          const double *sinv, const int *perm, const BtDevCsr &A, const BtDevEll &E, int n, const double *b, double *z, double *x,
+                          hipStream_t st)
 {
     BtStep s;
     int mx = 0;
@@ -319,7 +350,7 @@ void bt_launch_solve_step(const int r0[2], const int bs[2], const int blk[2], in
     s.nblk = nblk;
     const int gx = (mx + kSolveRows - 1) / kSolveRows;
     hipLaunchKernelGGL(bt_solve_kernel, dim3(gx, nblk), dim3(kCB), (size_t)mx * sizeof(double), st, s, mode, final_, ld, blk_stride, sinv, perm,
-                       A.rp, A.ci, A.v, b, z, x);
+                       A.rp, A.ci, A.v, E.k, n, E.ci, E.v, b, z, x);
 }
 
 void launch_cvt_f2d(int n, const float *in, double *out, hipStream_t st)

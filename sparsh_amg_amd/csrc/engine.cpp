@@ -616,13 +616,9 @@ bool Engine::setup_f32()
         return false;
     }
     if (nl < 2) return true;  // single level: the "V-cycle" is the direct solve, nothing to gain
-    // the float mirror exists for the sliced-diagonal layout; small coarse levels without it run a
-    // simple per-row fallback, but a large level without it would make the mode pointless
-    for (int l = 0; l + 1 < nl; ++l)
-        if (!lev_[l].A.has_sdia() && lev_[l].n > 100000) {
-            error = "precond_fp32 needs the sliced-diagonal layout on the large levels (level " + std::to_string(l) + " does not qualify)";
-            return false;
-        }
+    // levels with the sliced-diagonal mirror get a float copy of its value blocks (4 B per stored entry);
+    // every other level (unstructured operators, small coarse levels) a float copy of its CSR values
+    // (8 B per entry with the int32 column index) run by a row-per-thread kernel
     f32_.assign((size_t)nl, F32Level());
     for (int l = 0; l < nl; ++l) {
         DevLevel &d = lev_[l];
@@ -647,6 +643,10 @@ bool Engine::setup_f32()
                 f.A.val = static_cast<float *>(dalloc((size_t)d.A.sd_slots * 64 * 4));
                 if (!f.A.val) return false;
                 launch_cvt_d2f((long)d.A.sd_slots * 64, d.A.sd_val, f.A.val, st_);
+            } else {
+                f.csr_val = static_cast<float *>(dalloc((size_t)std::max(d.A.nnz, 1) * 4));
+                if (!f.csr_val) return false;
+                launch_cvt_d2f((long)d.A.nnz, d.A.val, f.csr_val, st_);
             }
         }
     }
@@ -674,7 +674,7 @@ void Engine::vcycle_f32(const double *r64, double *z64, double *partial, int *nb
         if (f.A.val)
             launch_sdia_f32(f.A, op, x, f.b, y, w, st_);
         else
-            launch_csr_f32(lev_[l].A, op, f.diag, x, f.b, y, w, st_);
+            launch_csr_f32(lev_[l].A, f.csr_val, op, f.diag, x, f.b, y, w, st_);
     };
     auto sweeps = [&](int l, int count) {
         F32Level &f = f32_[l];
@@ -706,6 +706,17 @@ void Engine::vcycle_f32(const double *r64, double *z64, double *partial, int *nb
         sweeps(l - 1, nu);
     }
     launch_cvt_f2d_dot(lev_[0].n, f32_[0].x, r64, z64, partial, nblk, st_);
+}
+
+bool Engine::op_precond_f32(const double *r, double *z)
+{
+    if (!f32_ready_) {
+        error = "the fp32 preconditioner hierarchy was not built (sparsh_params.precond_fp32 = 0, or a single level)";
+        return false;
+    }
+    int nb = 0;
+    vcycle_f32(r, z, part0_, &nb);
+    return true;
 }
 
 double Engine::read_scalar(int slot)

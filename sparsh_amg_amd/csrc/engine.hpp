@@ -42,6 +42,7 @@ struct KrylovState {
 // float mirror of one level for the opt-in fp32 preconditioner
 struct F32Level {
     SdiaF32 A;
+    float *csr_val = nullptr;  // float copy of the CSR values on levels without the sliced-diagonal mirror
     float *diag = nullptr, *x = nullptr, *x2 = nullptr, *b = nullptr, *r = nullptr;
 };
 
@@ -117,6 +118,8 @@ public:
     void op_restrict(int l, const double *r, double *bc);
     void op_prolong(int l, const double *xc, double *xf);
     void op_coarse(const double *b, double *x);
+    // z = V32(r): one application of the opt-in fp32 preconditioner (fp64 in/out); needs precond_fp32
+    bool op_precond_f32(const double *r, double *z);
     double op_dot(int n, const double *x, const double *y);
 
     // device memory helpers

@@ -164,13 +164,13 @@ __device__ __forceinline__ double row_epilogue(const CsrArgs &a, int row, double
 // loads in flight instead of one dependent col -> x chain at a time.
 // VEC: two entries per request through 16-B / 8-B loads at even indices (col/val carry kCsrPad
 // zeroed tail entries, so the pair stays in bounds).
-template <bool NT, bool VEC>
+template <bool NT, int VEC>
 __device__ __forceinline__ void stream_products(const int *__restrict__ col, const double *__restrict__ val,
                                                 const double *__restrict__ x, int j0, int j1, int t, int nthr,
                                                 double *__restrict__ prod)
 {
     if (j1 <= j0) return;
-    if constexpr (VEC) {
+    if constexpr (VEC > 0) {
         constexpr int U = 2;
         const int jb = j0 & ~1;
         const int jlast = (j1 - 1) & ~1;  // last valid even pair index
@@ -250,7 +250,7 @@ __device__ __forceinline__ double row_sum_lds(const double *__restrict__ prod, i
 
 // TAG: 1 for launches on the finest level.  Identical code; a distinct symbol lets profiler
 // summaries (rocprofv3 --stats) separate the dominant finest-level launches from coarse ones.
-template <int OP, bool NT, bool VEC, int TAG>
+template <int OP, bool NT, int VEC, int TAG>
 __global__ __launch_bounds__(kBlock) void csr_block_kernel(const int *__restrict__ rowblk, int nblk, int remap,
                                                             const int *__restrict__ rowptr, const int *__restrict__ col,
                                                             const double *__restrict__ val, CsrArgs a)
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(const int *__restrict
     }
 }
 
-template <int OP, bool NT, bool VEC, int TAG>
+template <int OP, bool NT, int VEC, int TAG>
 __global__ __launch_bounds__(kBlock) void csr_wave_kernel(const int *__restrict__ waveblk, int nwblk, int ngroups, int remap,
                                                            const int *__restrict__ rowptr, const int *__restrict__ col,
                                                            const double *__restrict__ val, CsrArgs a)
@@ -796,6 +796,28 @@ __device__ __forceinline__ double sdia_tab_apply_near(const SdTable &tab, const 
     return sum;
 }
 
+// a slice that is off its level's stencil table: through its record / slot headers (as in sdia_kernel)
+template <bool NT>
+__device__ __forceinline__ double sdia_offtable_row(int sl, int row, int lane, const double *__restrict__ x, const int *__restrict__ sd_ptr,
+                                                    const int *__restrict__ sd_off, const unsigned long long *__restrict__ sd_mask,
+                                                    const int *__restrict__ sd_vidx, const double *__restrict__ sd_cval,
+                                                    const double *__restrict__ sd_val, const int *__restrict__ sd_rec, double &dv)
+{
+    if (sd_rec) {
+        const SdRecord r = load_sd_record(sd_rec + (size_t)sl * kSdRecInts);
+        if (r.count >= 0) return sdia_row_rec(r, x, row, dv);
+    }
+    const int p0 = __builtin_amdgcn_readfirstlane(sd_ptr[sl]);
+    const int s0 = p0 & kSdPtrMask;
+    const int nd = (__builtin_amdgcn_readfirstlane(sd_ptr[sl + 1]) & kSdPtrMask) - s0;
+    if (p0 & kSdConstBit) return sdia_row_const(sd_off + s0, sd_mask + s0, sd_cval + s0, x, nd, row, dv);
+    if (p0 & kSdPlainBit) {
+        const int v0 = __builtin_amdgcn_readfirstlane(sd_vidx[s0]);
+        return sdia_row_plain<NT>(sd_off + s0, sd_mask + s0, sd_val + (size_t)v0 * 64 + lane, x, nd, row, lane, dv);
+    }
+    return sdia_row<NT>(sd_off + s0, sd_mask + s0, sd_vidx + s0, sd_cval + s0, sd_val + lane, x, nd, row, lane, dv);
+}
+
 template <int OP, bool NT, int TAG>
 __global__ __launch_bounds__(kBlock) void sdia_tab_kernel(int nrow, int xlen, int nslice, int ngroups, int remap, SdTable tab,
                                                            const int *__restrict__ slist,  // optional list of slices (interior / boundary launches)
@@ -849,33 +871,127 @@ __global__ __launch_bounds__(kBlock) void sdia_tab_kernel(int nrow, int xlen, in
             o.di = dv;
         } else {  // rare: a slice off the level's stencil goes through its record / slot headers
             if constexpr (op_needs_xi(OP)) o.xi = a.x[row];
-            bool done = false;
-            if (sd_rec) {
-                const SdRecord r = load_sd_record(sd_rec + (size_t)sl * kSdRecInts);
-                if (r.count >= 0) {
-                    sum = sdia_row_rec(r, a.x, row, o.di);
-                    done = true;
-                }
-            }
-            if (!done) {
-                const int p0 = __builtin_amdgcn_readfirstlane(sd_ptr[sl]);
-                const int s0 = p0 & kSdPtrMask;
-                const int nd = (__builtin_amdgcn_readfirstlane(sd_ptr[sl + 1]) & kSdPtrMask) - s0;
-                if (p0 & kSdConstBit) {
-                    sum = sdia_row_const(sd_off + s0, sd_mask + s0, sd_cval + s0, a.x, nd, row, o.di);
-                } else if (p0 & kSdPlainBit) {
-                    const int v0 = __builtin_amdgcn_readfirstlane(sd_vidx[s0]);
-                    sum = sdia_row_plain<NT>(sd_off + s0, sd_mask + s0, sd_val + (size_t)v0 * 64 + lane, a.x, nd, row, lane, o.di);
-                } else {
-                    sum = sdia_row<NT>(sd_off + s0, sd_mask + s0, sd_vidx + s0, sd_cval + s0, sd_val + lane, a.x, nd, row, lane, o.di);
-                }
-            }
+            sum = sdia_offtable_row<NT>(sl, row, lane, a.x, sd_ptr, sd_off, sd_mask, sd_vidx, sd_cval, sd_val, sd_rec, o.di);
         }
         if (has_row) acc = row_epilogue<OP>(a, row, sum, o);
     }
     if constexpr (op_reduces(OP)) {
         const double t = block_sum(acc, red);
         if (threadIdx.x == 0) a.partial[a.partial_off + gid] = t;
+    }
+}
+
+// LDS-tiled table path ("sdia_tile_kernel").  The table kernel above is bound by the bytes L2 delivers
+// to the CUs: every row pulls x[r], x[r +- line], x[r +- plane] through L1 (~49 B/row of reads, every
+// far gather an L1 miss; profiles/r01_pmc_diag/).  Here a workgroup of 16 waves owns T = 1024 S consecutive
+// rows; every wave loads the centre values of its own slices (coalesced, kept in registers) and parks
+// them in LDS, the first threads add the halo x[r0 - line, r0) and x[r0 + T, r0 + T + line) (north_star:
+// "LDS staging of x-vector tiles"): after one barrier the +-1 and +-line neighbours of every row come out
+// of LDS, only the +-plane neighbours (3D stencils) are still gathered from L2 -- issued, like b and the
+// lane masks, before the barrier so their latency overlaps the staging.  Reads per row:
+// 8 (1 + 2 line / T) + 16 + 8 (b) + 1 (masks) ~ 36 B instead of 49.  Same products, same order of additions
+// as every other family.  Launch: whole level only (no slice lists); LDS = (T + lo + hi) doubles.
+constexpr int kTileBlock = 1024;
+
+template <int OP, int ND, int S, int TAG>
+__global__ __launch_bounds__(kTileBlock) void sdia_tile_kernel(int nrow, int xlen, int ntile, int remap, SdTable tab,
+                                                                const unsigned long long *__restrict__ sd_tmask, const int *__restrict__ sd_tconf,
+                                                                const int *__restrict__ sd_ptr, const int *__restrict__ sd_off,
+                                                                const unsigned long long *__restrict__ sd_mask, const int *__restrict__ sd_vidx,
+                                                                const double *__restrict__ sd_cval, const double *__restrict__ sd_val,
+                                                                const int *__restrict__ sd_rec, CsrArgs a)
+{
+    extern __shared__ double xt[];
+    __shared__ double red[kTileBlock / 64];
+    constexpr int C0 = ND / 2;
+    constexpr int T = kTileBlock * S;
+    constexpr int NW = kTileBlock / 64;
+    const int tile = remap ? xcd_remap(blockIdx.x, ntile, remap) : blockIdx.x;
+    if (tile >= ntile) return;  // whole workgroup leaves together
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lo = -tab.off[C0 - 2], hi = tab.off[C0 + 2];  // reach of the +-line neighbours (kernel arguments)
+    const int r0 = tile * T;
+    const double *__restrict__ x = a.x;
+    int row[S];
+    bool valid[S], has_row[S], conform[S];
+    unsigned long long m[S][ND];
+    RowOperands o[S];
+    double xc[S], xm[S], xp[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int k = w + NW * s;
+        const int sl = (r0 >> 6) + k;
+        valid[s] = sl * 64 < nrow;  // wave-uniform
+        const int slc = valid[s] ? sl : 0;
+        int r = slc * 64 + lane;
+        has_row[s] = valid[s] && r < nrow;
+        if (r >= nrow) r = nrow - 1;
+        row[s] = r;
+        const unsigned long long *mrec = sd_tmask + (size_t)slc * 8;
+#pragma unroll
+        for (int u = 0; u < ND; ++u) m[s][u] = mrec[u];  // wave-uniform: scalar loads
+        conform[s] = __builtin_amdgcn_readfirstlane(sd_tconf[slc]) != 0;
+        if (has_row[s]) o[s] = load_row_operands<OP, false, false>(a, r);
+        xm[s] = 0.0;
+        xp[s] = 0.0;
+        if constexpr (ND == 7) {  // +-plane neighbours: gathered through L1/L2, in flight across the barrier
+            const int im = r + tab.off[0], ip = r + tab.off[6];
+            xm[s] = x[(unsigned)im < (unsigned)xlen ? im : r];
+            xp[s] = x[(unsigned)ip < (unsigned)xlen ? ip : r];
+        }
+        xc[s] = x[r];
+        xt[lo + k * 64 + lane] = xc[s];
+    }
+    // halo of the window: x[r0 - lo, r0) in front, x[r0 + T, r0 + T + hi) behind (clamped into the vector;
+    // entries outside it are never used: the lane masks of rows that would need them are clear)
+    for (int i = threadIdx.x; i < lo + hi; i += kTileBlock) {
+        const int idx = i < lo ? r0 - lo + i : r0 + T + (i - lo);
+        const int pos = i < lo ? i : T + i;
+        xt[pos] = x[idx < 0 ? 0 : (idx < xlen ? idx : xlen - 1)];
+    }
+    __syncthreads();
+    double acc = 0.0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (!valid[s]) continue;  // wave-uniform
+        const int r = row[s];
+        double sum = 0.0;
+        if (conform[s]) {
+            const int li = lo + (r - r0);  // position of the row inside the window
+            double xv[ND];
+            if constexpr (ND == 7) {
+                xv[0] = xm[s];
+                xv[6] = xp[s];
+            }
+            xv[C0 - 2] = xt[li - lo];
+            xv[C0 - 1] = xt[li - 1];
+            xv[C0] = xc[s];
+            xv[C0 + 1] = xt[li + 1];
+            xv[C0 + 2] = xt[li + hi];
+#pragma unroll
+            for (int u = 0; u < ND; ++u) {
+                const bool on = __builtin_amdgcn_inverse_ballot_w64(m[s][u]);
+                const double t = tab.cval[u] * xv[u];
+                sum = on ? sum + t : sum;
+            }
+            o[s].di = __builtin_amdgcn_inverse_ballot_w64(m[s][C0]) ? tab.cval[C0] : 0.0;
+            if constexpr (op_needs_xi(OP)) o[s].xi = xc[s];
+        } else {  // rare: a slice off the level's stencil goes through its record / slot headers
+            if constexpr (op_needs_xi(OP)) o[s].xi = xc[s];
+            sum = sdia_offtable_row<false>(r >> 6, r, lane, x, sd_ptr, sd_off, sd_mask, sd_vidx, sd_cval, sd_val, sd_rec, o[s].di);
+        }
+        if (has_row[s]) acc += row_epilogue<OP>(a, r, sum, o[s]);
+    }
+    if constexpr (op_reduces(OP)) {
+        acc = wave_sum(acc);
+        if (lane == 0) red[w] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) t += red[q];
+            a.partial[a.partial_off + tile] = t;
+        }
     }
 }
 
@@ -969,17 +1085,17 @@ __global__ __launch_bounds__(kBlock) void csr_rows_f32_kernel(int n, const int *
     }
 }
 
-// fallback for (small, coarse) levels without a sliced-diagonal mirror: one thread per CSR row,
-// fp64 values converted on the fly
+// levels without a sliced-diagonal mirror (unstructured operators, small coarse levels): one thread per
+// CSR row over a float copy of the values (8 B per entry instead of 12)
 template <int OP>
 __global__ __launch_bounds__(kBlock) void csr_f32_kernel(int n, const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                          const double *__restrict__ val, const float *__restrict__ diag,
+                                                          const float *__restrict__ val, const float *__restrict__ diag,
                                                           const float *__restrict__ x, const float *__restrict__ b, float *__restrict__ y,
                                                           float omega)
 {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         float s = 0.f;
-        for (int j = rowptr[i]; j < rowptr[i + 1]; ++j) s += (float)val[j] * x[col[j]];
+        for (int j = rowptr[i]; j < rowptr[i + 1]; ++j) s += val[j] * x[col[j]];
         const float h = b[i] - s;
         if constexpr (OP == OP_JACOBI)
             y[i] = x[i] + omega * h / diag[i];
@@ -1032,6 +1148,27 @@ int launch_csr_tagged(const DevCsr &A, const CsrArgs &a, bool nt, int remap, hip
 {
     const CsrFamily fam = csr_family(A, c);
     if (fam == FAM_SDIA_TAB) {
+        const int T = sdia_tile_rows(A, c);
+        if (T > 0 && !a.slice_list) {  // LDS-tiled variant: whole-level launches of grid stencils
+            const int ntile = (A.nrow + T - 1) / T;
+            const int C0 = A.sd_tab.nd / 2;
+            const size_t lds = (size_t)(T - A.sd_tab.off[C0 - 2] + A.sd_tab.off[C0 + 2]) * sizeof(double);
+            const int grid = remap_grid(ntile, remap);
+#define SPARSH_LAUNCH_TILE(ND_, S_) \
+    hipLaunchKernelGGL((sdia_tile_kernel<OP, ND_, S_, TAG>), dim3(grid), dim3(kTileBlock), lds, st, A.nrow, A.ncol, ntile, remap, A.sd_tab, A.sd_tmask, A.sd_tconf, A.sd_ptr, A.sd_off, A.sd_mask, A.sd_vidx, A.sd_cval, A.sd_val, A.sd_rec, a)
+            const int S = T / kTileBlock;
+            if (A.sd_tab.nd == 7) {
+                if (S == 1) SPARSH_LAUNCH_TILE(7, 1);
+                else if (S == 2) SPARSH_LAUNCH_TILE(7, 2);
+                else SPARSH_LAUNCH_TILE(7, 4);
+            } else {
+                if (S == 1) SPARSH_LAUNCH_TILE(5, 1);
+                else if (S == 2) SPARSH_LAUNCH_TILE(5, 2);
+                else SPARSH_LAUNCH_TILE(5, 4);
+            }
+#undef SPARSH_LAUNCH_TILE
+            return ntile;
+        }
         const int nwork = a.slice_list ? a.nlist : A.nslice;
         const int ngroups = (nwork + 3) / 4;
         if (ngroups <= 0) return 0;
@@ -1068,10 +1205,10 @@ int launch_csr_tagged(const DevCsr &A, const CsrArgs &a, bool nt, int remap, hip
         const int grid = remap_grid(ngroups, remap);
 #define SPARSH_LAUNCH_WAVE(NT_, VEC_) \
     hipLaunchKernelGGL((csr_wave_kernel<OP, NT_, VEC_, TAG>), dim3(grid), dim3(kBlock), 0, st, A.waveblk, A.nwblk, ngroups, remap, A.rowptr, A.col, A.val, a)
-        if (nt && c.vec) SPARSH_LAUNCH_WAVE(true, true);
-        else if (nt) SPARSH_LAUNCH_WAVE(true, false);
-        else if (c.vec) SPARSH_LAUNCH_WAVE(false, true);
-        else SPARSH_LAUNCH_WAVE(false, false);
+        if (nt && c.vec) SPARSH_LAUNCH_WAVE(true, 1);
+        else if (nt) SPARSH_LAUNCH_WAVE(true, 0);
+        else if (c.vec) SPARSH_LAUNCH_WAVE(false, 1);
+        else SPARSH_LAUNCH_WAVE(false, 0);
 #undef SPARSH_LAUNCH_WAVE
         return ngroups;
     }
@@ -1079,10 +1216,10 @@ int launch_csr_tagged(const DevCsr &A, const CsrArgs &a, bool nt, int remap, hip
     const int grid = remap_grid(A.nblk, remap);
 #define SPARSH_LAUNCH_BLOCK(NT_, VEC_) \
     hipLaunchKernelGGL((csr_block_kernel<OP, NT_, VEC_, TAG>), dim3(grid), dim3(kBlock), 0, st, A.rowblk, A.nblk, remap, A.rowptr, A.col, A.val, a)
-    if (nt && c.vec) SPARSH_LAUNCH_BLOCK(true, true);
-    else if (nt) SPARSH_LAUNCH_BLOCK(true, false);
-    else if (c.vec) SPARSH_LAUNCH_BLOCK(false, true);
-    else SPARSH_LAUNCH_BLOCK(false, false);
+    if (nt && c.vec) SPARSH_LAUNCH_BLOCK(true, 1);
+    else if (nt) SPARSH_LAUNCH_BLOCK(true, 0);
+    else if (c.vec) SPARSH_LAUNCH_BLOCK(false, 1);
+    else SPARSH_LAUNCH_BLOCK(false, 0);
 #undef SPARSH_LAUNCH_BLOCK
     return A.nblk;
 }
@@ -1099,6 +1236,23 @@ CsrFamily csr_family(const DevCsr &A, const KernelConfig &c)
     if (c.kind >= 2 && A.sell_val) return FAM_SELL;
     if (c.kind == 1 && A.waveblk) return FAM_CSR_WAVE;
     return FAM_CSR_BLOCK;
+}
+
+// rows per workgroup of the LDS-tiled table kernel for this operator, 0 when it does not apply: grid
+// stencils in lexicographic order (offsets -1, 0, +1 adjacent in the middle of a 5- or 7-entry table) whose
+// +-line reach is small enough for the window [r0 - line, r0 + T + line) to fit 64 KiB of LDS with at most
+// ~50 % of halo
+int sdia_tile_rows(const DevCsr &A, const KernelConfig &c)
+{
+    if (!c.tile || !A.sd_tmask || (A.sd_tab.near != 73 && A.sd_tab.near != 52)) return 0;
+    const int C0 = A.sd_tab.nd / 2;
+    const int lo = -A.sd_tab.off[C0 - 2], hi = A.sd_tab.off[C0 + 2];
+    if (lo < 2 || hi < 2) return 0;
+    if (A.sd_tab.nd == 7 && (-A.sd_tab.off[0] <= lo || A.sd_tab.off[6] <= hi)) return 0;
+    if (A.nrow < 65536) return 0;  // small levels are launch-latency bound either way: keep one slice per wave
+    const int reach = lo + hi;
+    const int T = reach <= 512 ? 1024 : (reach <= 1024 ? 2048 : (reach <= 2048 ? 4096 : 0));
+    return T;
 }
 
 const char *csr_family_name(CsrFamily f)
@@ -1646,13 +1800,15 @@ void launch_sdia_f32(const SdiaF32 &A, CsrOp op, const float *x, const float *b,
         hipLaunchKernelGGL((sdia_f32_kernel<OP_RESID>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.nslice, ngroups, remap, A.sd_ptr, A.sd_off, A.sd_mask, A.val, x, b, y, omega);
 }
 
-void launch_csr_f32(const DevCsr &A, CsrOp op, const float *diag, const float *x, const float *b, float *y, float omega, hipStream_t st)
+void launch_csr_f32(const DevCsr &A, const float *val32, CsrOp op, const float *diag, const float *x, const float *b, float *y, float omega,
+                    hipStream_t st)
 {
     if (A.nrow <= 0) return;
+    const int grid = (A.nrow + kBlock - 1) / kBlock;  // one row per thread: no grid-stride tail on large levels
     if (op == OP_JACOBI)
-        hipLaunchKernelGGL((csr_f32_kernel<OP_JACOBI>), dim3(ew_grid(A.nrow)), dim3(kBlock), 0, st, A.nrow, A.rowptr, A.col, A.val, diag, x, b, y, omega);
+        hipLaunchKernelGGL((csr_f32_kernel<OP_JACOBI>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.rowptr, A.col, val32, diag, x, b, y, omega);
     else
-        hipLaunchKernelGGL((csr_f32_kernel<OP_RESID>), dim3(ew_grid(A.nrow)), dim3(kBlock), 0, st, A.nrow, A.rowptr, A.col, A.val, diag, x, b, y, omega);
+        hipLaunchKernelGGL((csr_f32_kernel<OP_RESID>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.rowptr, A.col, val32, diag, x, b, y, omega);
 }
 
 void launch_jacobi_zero_f32(int n, const float *b, const float *d, float omega, float *x, hipStream_t st)

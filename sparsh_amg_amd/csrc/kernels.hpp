@@ -76,11 +76,12 @@ struct DevCsr {
 struct KernelConfig {
     int kind = 3;       // 0 workgroup CSR-stream, 1 wave CSR-stream, 2 sliced ELL, 3 sliced diagonals; 2 and 3 fall
                         // back (3 -> 2 -> 0) where the operator does not qualify for the mirror
-    bool vec = true;    // phase 1 reads two entries per lane (16-B val / 8-B col loads)
+    int vec = 1;        // phase 1 of the CSR-stream kernels: 0 one entry per load, 1 two entries per lane (16-B val / 8-B col loads)
     bool auto_policy = true;  // choose nt / remap per operator from its size (overrides the two below)
     bool nt = true;     // non-temporal loads for the matrix stream
     int remap = 1;      // 0 none, 1 XCD x owns the x-th contiguous eighth, G>1 groups of G row blocks dealt round-robin to XCDs
     bool table = true;  // use the level-wide stencil table where a level has one
+    bool tile = false;  // table levels of grid stencils: stage x tiles in LDS (sdia_tile_kernel) on whole-level launches
     bool const_slots = true;  // layout option read at setup: fold constant diagonals of a slice into one scalar
 };
 
@@ -131,6 +132,7 @@ int build_waveblocks(int nrow, const int *rowptr, int *out);
 int launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool finest, hipStream_t st, const KernelConfig &cfg);
 CsrFamily csr_family(const DevCsr &A, const KernelConfig &cfg);
 const char *csr_family_name(CsrFamily f);
+int sdia_tile_rows(const DevCsr &A, const KernelConfig &cfg);  // rows per workgroup of the LDS-tiled table kernel, 0 = not used
 // placement the launcher picks for A under cfg: non-temporal matrix stream, XCD remap mode
 void csr_placement(const DevCsr &A, const KernelConfig &cfg, bool *nt, int *remap);
 
@@ -164,8 +166,9 @@ struct SdiaF32 {
 };
 // op: OP_JACOBI (y = x + omega (b - A x)/d) or OP_RESID (y = b - A x); all vectors float
 void launch_sdia_f32(const SdiaF32 &A, CsrOp op, const float *x, const float *b, float *y, float omega, hipStream_t st);
-// same two ops for a level that has no sliced-diagonal mirror (thread per CSR row; coarse levels only)
-void launch_csr_f32(const DevCsr &A, CsrOp op, const float *diag, const float *x, const float *b, float *y, float omega, hipStream_t st);
+// same two ops for a level that has no sliced-diagonal mirror (thread per CSR row over a float copy of the values)
+void launch_csr_f32(const DevCsr &A, const float *val32, CsrOp op, const float *diag, const float *x, const float *b, float *y, float omega,
+                    hipStream_t st);
 void launch_jacobi_zero_f32(int n, const float *b, const float *d, float omega, float *x, hipStream_t st);
 void launch_restrict_f32(int nc, const int *rowptr, const int *col, const double *val, const float *r, float *bc, hipStream_t st);
 void launch_prolong_agg_f32(int n, const int *agg, const float *xc, float *xf, hipStream_t st);

@@ -461,3 +461,62 @@ def test_sliced_diagonal_paths_fuzz():
         finally:
             H.close()
     assert {"sdia_tab_kernel", "sdia_kernel"} <= kernels_seen, kernels_seen
+
+
+def _box3d(nx, ny, nz):
+    """7-pt Laplacian on an nx x ny x nz box (x fastest): line offset nx, plane offset nx*ny."""
+    import scipy.sparse as sp
+
+    def lap(n):
+        return sp.diags([-np.ones(n - 1), 2.0 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1])
+
+    A = (sp.kron(sp.identity(nz), sp.kron(sp.identity(ny), lap(nx))) + sp.kron(sp.identity(nz), sp.kron(lap(ny), sp.identity(nx)))
+         + sp.kron(lap(nz), sp.identity(nx * ny))).tocsr()
+    A.sort_indices()
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+
+
+@pytest.mark.parametrize("name,gen", [
+    ("p3d_48", lambda: problems.poisson3d(48)),            # line 48, plane 2304
+    ("box_70x40x37", lambda: _box3d(70, 40, 37)),           # line 70 (not a multiple of anything), ragged last tile
+    ("p2d_300", lambda: problems.poisson2d(300)),          # 5-pt: every neighbour from LDS
+    ("p2d_700", lambda: problems.poisson2d(700)),          # line 700: 2048-row tiles
+])
+def test_lds_tiled_table_kernel_bitwise(name, gen):
+    """sdia_tile_kernel (x tiles staged in LDS; opt-in, see DESIGN.md: measured slower than the untiled
+    table kernel) against the oracle and against the untiled table kernel, bit for bit, for every
+    epilogue, on every level that uses it; fused reductions to 1e-12."""
+    rp, ci, v = gen()
+    n = len(rp) - 1
+    A = sa.sp_matrix_mg(rp, ci, v).set_tile(True).setup(sa.default_params(**QUIET))
+    B = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET))  # default: untiled
+    O = oracle.Csr(rp, ci, v)
+    H = oracle.Hierarchy(O)
+    rng = np.random.default_rng(41)
+    tiled_levels = [l for l in range(A.nlevels) if A.level_tile_rows(l) > 0]
+    assert 0 in tiled_levels and A.level_kernel(0) == "sdia_tab_kernel", (name, tiled_levels)
+    assert all(B.level_tile_rows(l) == 0 for l in range(B.nlevels))
+    for l in tiled_levels:
+        nl = A.level_info(l)["nrow"]
+        x, b = rng.standard_normal(nl), rng.standard_normal(nl)
+        Ol = H.A(l)
+        ya = A.op_spmv(l, x)
+        assert np.array_equal(ya, oracle.spmv(Ol, x)) and np.array_equal(ya, B.op_spmv(l, x)), (name, l)
+        assert np.array_equal(A.op_residual(l, b, x), oracle.store_residual(Ol, b, x)), (name, l)
+        for sweeps in (1, 3):
+            assert np.array_equal(A.op_jacobi(l, b, x, sweeps), oracle.jacobi(Ol, b, x, sweeps - 1)), (name, l, sweeps)
+        rn = A.op_resnorm(l, b, x)
+        assert abs(rn - oracle.residual(Ol, b, x)) <= 1e-12 * rn
+        if l + 1 < A.nlevels:
+            xc = rng.standard_normal(A.level_info(l + 1)["nrow"])
+            assert np.array_equal(A.op_prolong(l, xc, x), oracle.transfer_solution(H.P(l), xc, x))
+    bb = np.ones(n)
+    xa, xb = np.zeros(n), np.zeros(n)
+    ha, rca = A.solve("pcg", bb, xa)
+    hb, rcb = B.solve("pcg", bb, xb)
+    assert rca == 0 and rcb == 0 and len(ha) == len(hb)
+    assert np.allclose(ha, hb, rtol=1e-9)  # fused dot products are summed per tile instead of per 4 slices
+    xo, ho = oracle.solve("pcg", O, bb)
+    _hist_ok(ha, ho)
+    A.close()
+    B.close()

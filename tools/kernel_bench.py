@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--vlevels", type=int, nargs="*", default=[0, 2, 4])
     ap.add_argument("--no-const", action="store_true", help="build the sliced-diagonal layout without constant-slot folding")
     ap.add_argument("--kinds", type=int, nargs="*", default=[3, 2], help="kernel families of the --remaps sweep")
+    ap.add_argument("--tile-ab", action="store_true", help="A/B the LDS-tiled table kernel against the untiled one, level by level (interleaved rounds)")
     a = ap.parse_args()
     if a.fem:
         rp, ci, v = problems.fem_unstructured(a.fem, ordering=a.ordering)
@@ -57,7 +58,7 @@ def main():
         return
     if a.variants:
         print(f"{'config':28s} {'op':8s} {'lvl':>3s} {'us':>9s} {'GB/s':>8s} {'frac8T':>7s}")
-        cfgs = [(k, v, nt, rm) for k in (0, 1, 2, 3) for v in ((0, 1) if k < 2 else (0,)) for nt in (1, 0) for rm in (1, 16)]
+        cfgs = [(k, v, nt, rm) for k in a.kinds for v in ((0, 1) if k < 2 else (0,)) for nt in (1, 0) for rm in (1, 16)]
         for rnd in range(a.rounds):
             for (k, v, nt, rm) in cfgs:
                 A.set_kernel_config(kind=k, vec=v, nt=nt, remap=rm)
@@ -71,6 +72,23 @@ def main():
                         gbs = nbytes / sec / 1e9
                         print(f"kind={k} vec={v} nt={nt} remap={rm} r{rnd:<3d} {op:8s} {l:3d} {sec * 1e6:9.1f} {gbs:8.1f} {gbs / 8000:7.3f}", flush=True)
         A.set_kernel_config()
+        return
+    if a.tile_ab:
+        A.set_tile(True)
+        print("tile rows per level:", [A.level_tile_rows(l) for l in range(A.nlevels)])
+        print(f"{'op':9s} {'lvl':>3s} {'rows':>10s} {'tiled us':>9s} {'plain us':>9s} {'ratio':>6s}")
+        for l in range(min(a.levels, A.nlevels)):
+            A.set_tile(True)
+            if A.level_tile_rows(l) == 0:
+                continue
+            for op in ("jacobi", "spmv", "residual"):
+                tt, tp = [], []
+                for rnd in range(a.rounds):
+                    A.set_tile(True)
+                    tt.append(A.bench_op(op, l, a.reps))
+                    A.set_tile(False)
+                    tp.append(A.bench_op(op, l, a.reps))
+                print(f"{op:9s} {l:3d} {A.level_info(l)['nrow']:10d} {min(tt) * 1e6:9.2f} {min(tp) * 1e6:9.2f} {min(tt) / min(tp):6.3f}", flush=True)
         return
     print("level formats (3 sliced diagonals, 2 sliced ELL, 0 CSR-stream):", [A.level_format(l)[0] for l in range(A.nlevels)])
     print("sliced-diagonal slots / value blocks per level:", [A.level_layout(l) for l in range(A.nlevels)])
