@@ -388,13 +388,14 @@ class sp_matrix_mg:
         rc = _check(lib.sparsh_vcycle(self._h, _dp(b), _dp(x), iterations, _dp(hist), hist_cap, C.byref(n)), allow=(SPARSH_ENOCONV,))
         return hist[: min(n.value, hist_cap)].copy(), rc
 
-    def solve(self, method, b, x, hist_cap=8192):
+    def solve(self, method, b, x, hist_cap=8192, allow=()):
+        """allow: extra return codes handed back instead of raised (SPARSH_ENOCONV always is)."""
         b = np.ascontiguousarray(b, dtype=np.float64)
         assert x.dtype == np.float64 and x.flags.c_contiguous
         hist = np.zeros(hist_cap)
         n = C.c_int()
         m = METHODS[method] if isinstance(method, str) else method
-        rc = _check(lib.sparsh_solve(self._h, m, _dp(b), _dp(x), _dp(hist), hist_cap, C.byref(n)), allow=(SPARSH_ENOCONV,))
+        rc = _check(lib.sparsh_solve(self._h, m, _dp(b), _dp(x), _dp(hist), hist_cap, C.byref(n)), allow=(SPARSH_ENOCONV,) + tuple(allow))
         return hist[: min(n.value, hist_cap)].copy(), rc
 
     # -- device-resident path (bench) ------------------------------------------------------
@@ -455,7 +456,8 @@ class sp_matrix_mg:
         return dict(launches=int(out[0]), seconds=out[1], nrow=int(out[2]), nnz=int(out[3]))
 
     def bench_op(self, op, level=0, reps=20):
-        ops = {"spmv": 0, "jacobi": 1, "residual": 2, "restrict": 3, "prolong": 4, "coarse": 5, "dot": 6, "axpby": 7, "copy_int": 8}
+        ops = {"spmv": 0, "jacobi": 1, "residual": 2, "restrict": 3, "prolong": 4, "coarse": 5, "dot": 6, "axpby": 7, "copy_int": 8,
+               "jacobi_pingpong": 9, "jacobi_pingpong_resident": 10}
         sec = C.c_double()
         _check(lib.sparsh_bench_op(self._h, ops[op] if isinstance(op, str) else op, level, reps, C.byref(sec)))
         return sec.value

@@ -723,10 +723,23 @@ int sparsh_bench_op(sparsh_handle h, int op, int level, int reps, double *avg_se
         } break;
         case 7: launch_axpby((int)n, 0.5, x.p, 0.5, y.p, st); break;
         case 8: launch_copy_int((int)n, L.A.rowptr, reinterpret_cast<int *>(y.p), st); break;  // n int32: reads 4n, writes 4n
+        case 9:    // fused Jacobi sweeps the way a smoothing leg issues them: ping-pong between two vectors
+        case 10: { // ... on the level's own resident buffers (x, x2, r as the right-hand side)
+            static thread_local int flip = 0;
+            double *xa = op == 9 ? x.p : L.x, *xb = op == 9 ? y.p : L.x2;
+            CsrArgs a;
+            a.x = (flip & 1) ? xb : xa;
+            a.y = (flip & 1) ? xa : xb;
+            a.b = op == 9 ? b.p : L.r;
+            a.d = L.diag;
+            a.omega = E.params().omega;
+            ++flip;
+            launch_csr(L.A, OP_JACOBI, a, L.fine, st, E.kernel_cfg());
+        } break;
         default: break;
         }
     };
-    if (op < 0 || op > 8) return fail(SPARSH_EINVAL, "unknown op");
+    if (op < 0 || op > 10) return fail(SPARSH_EINVAL, "unknown op");
     for (int i = 0; i < 3; ++i) run();
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);

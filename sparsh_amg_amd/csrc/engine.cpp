@@ -891,7 +891,9 @@ void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, doubl
         launch_jacobi_zero(L.n, b, L.diag, prm_.omega, L.x, st_);
         k = 1;
     }
-    const bool timed = prof.enabled && &L == &lev_[0];
+    const bool timed = prof.enabled && &L == &lev_[0] && k < sweeps && prof.used + 2 <= prof.ev.size();
+    if (timed) HIPCHK(hipEventRecord(prof.ev[prof.used], st_));
+    int in_run = 0;
     for (; k < sweeps; ++k) {
         const bool last = (k == sweeps - 1);
         CsrArgs a;
@@ -906,12 +908,15 @@ void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, doubl
             a.partial = dot_partial;
             dot_done = true;
         }
-        const bool rec = timed && prof.used + 2 <= prof.ev.size();
-        if (rec) HIPCHK(hipEventRecord(prof.ev[prof.used++], st_));
         const int np = apply_A(L, op, a);
         if (op == OP_JACOBI_DOT) *dot_nblk = np;
-        if (rec) HIPCHK(hipEventRecord(prof.ev[prof.used++], st_));
+        ++in_run;
         std::swap(L.x, L.x2);
+    }
+    if (timed) {
+        HIPCHK(hipEventRecord(prof.ev[prof.used + 1], st_));
+        prof.run_launches.push_back(in_run);
+        prof.used += 2;
     }
     if (dot_partial && !dot_done) launch_dot(L.n, L.x, b, dot_partial, dot_nblk, st_);
 }
@@ -1231,6 +1236,7 @@ void Engine::profile_begin()
         for (auto &e : prof.ev) HIPCHK(hipEventCreate(&e));
     }
     prof.used = 0;
+    prof.run_launches.clear();
     prof.launches = 0;
     prof.seconds = 0;
 }
@@ -1244,7 +1250,7 @@ void Engine::profile_collect()
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, prof.ev[k], prof.ev[k + 1]) == hipSuccess) {
             prof.seconds += ms * 1e-3;
-            prof.launches += 1;
+            prof.launches += k / 2 < prof.run_launches.size() ? prof.run_launches[k / 2] : 1;
         }
     }
 }

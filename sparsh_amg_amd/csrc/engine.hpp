@@ -53,9 +53,14 @@ struct GraphState {
     bool precond = false;
 };
 
+// HIP-event timing of the dominant kernel inside a solve: one event pair brackets each RUN of consecutive
+// fused Jacobi launches on the finest level (the 6-7 sweeps of a smoothing leg), so the cost of the event
+// packets themselves is spread over the run instead of being charged to every launch (an event pair
+// around each single launch reads ~10 us high).
 struct ProfileData {
     bool enabled = false;
-    std::vector<hipEvent_t> ev;  // pairs
+    std::vector<hipEvent_t> ev;      // pairs
+    std::vector<int> run_launches;   // launches bracketed by pair k
     size_t used = 0;
     double launches = 0, seconds = 0;
 };

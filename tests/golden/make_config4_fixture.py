@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/config4_fem_oracle.json: the CPU oracle (oracle/amg_oracle.c, restating
+Solver_PBiCG_1 / Solver_PCG_1 of the reference, src/AMG_main_solvers.cpp:358-458, 107-167) on the FULL-SIZE
+BASELINE configs[4] stand-in -- P1-FEM  M + dt K  on a Delaunay mesh of 525 825 points
+(sparsh_amg_amd.problems.fem_unstructured, seed 20240607, dt = 1e-2; SuiteSparse parabolic_fem itself is not
+in the image).  Two right-hand sides:
+  * b = 1e-3 (constant): AMG-BiCGStab BREAKS DOWN (the constant vector is almost an eigenvector of
+    M + dt K, the shadow residual r0 stays parallel to it and r.r0 / (Ap.r0) ends as 0/0; the reference
+    has no breakdown checks: `while (res > tol1)`, src/AMG_main_solvers.cpp:397) -- the residual becomes NaN;
+  * b = 1e-3 * N(0,1) (numpy default_rng(4)): converges.
+Takes ~6 minutes of 8-thread CPU time.  Data only: iteration counts, residual heads/tails, solution checks."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+from sparsh_amg_amd import problems  # noqa: E402
+
+
+def main():
+    rp, ci, v = problems.fem_unstructured(525825)
+    n = len(rp) - 1
+    O = oracle.Csr(rp, ci, v)
+    out = {"_provenance": "oracle/amg_oracle.c run by tests/golden/make_config4_fixture.py (CPU restatement of the reference algorithm; "
+                          "NOT an output of the reference itself: parity unpinned for this input)",
+           "input": "problems.fem_unstructured(525825), seed 20240607, dt 1e-2, morton ordering", "nrow": n, "nnz": int(rp[-1])}
+    prm = oracle.params(threads=8, max_iter=2000)
+    for key, b in (("constant_rhs", np.full(n, 1e-3)), ("random_rhs", np.random.default_rng(4).standard_normal(n) * 1e-3)):
+        for method in ("pbicg", "pcg"):
+            x, h = oracle.solve(method, O, b, prm=prm)
+            nan_at = int(np.flatnonzero(~np.isfinite(h))[0]) if np.any(~np.isfinite(h)) else None
+            out.setdefault(key, {})[method] = {
+                "iterations": len(h), "first_nonfinite": nan_at, "hist_head": [float(t) for t in h[:12]],
+                "hist_tail": [float(t) if np.isfinite(t) else None for t in h[-3:]],
+                "xnorm": float(np.linalg.norm(x)) if np.all(np.isfinite(x)) else None,
+                "x_head": [float(t) if np.isfinite(t) else None for t in x[:4]]}
+            print(key, method, len(h), nan_at, h[-3:], flush=True)
+    with open(os.path.join(ROOT, "tests", "golden", "config4_fem_oracle.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -25,15 +25,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 N_GRID = 216
 
 
-def run(grid=N_GRID, cfg=None, no_fold=False, layout_out=None):
+def run(grid=N_GRID, cfg=None, no_fold=False, layout_out=None, fem=0):
     import sparsh_amg_amd as sa
     from sparsh_amg_amd import problems
 
-    rp, ci, v = problems.poisson3d(grid)
+    rp, ci, v = problems.fem_unstructured(fem) if fem else problems.poisson3d(grid)
     A = sa.sp_matrix_mg(rp, ci, v)
     if no_fold:
         A.set_const_slots(False)
-    A.setup(sa.default_params(print_setup=0, print_solve=0))
+    # coarse_limit = 8192: keep the coarsest level on the dense-inverse path here; the block-tridiagonal
+    # factorisation issues tens of thousands of small launches, which the counter-collection mode of the
+    # profiler does not survive (segfault inside rocprofv3); the finest-level kernels measured are unaffected
+    A.setup(sa.default_params(print_setup=0, print_solve=0, coarse_limit=8192))
     cfg = cfg or os.environ.get("SPARSH_PMC_CFG")  # "kind,vec,nt,remap": override the per-operator policy (diagnostics)
     if cfg:
         A.set_kernel_config(*[int(t) for t in cfg.split(",")])
@@ -45,7 +48,8 @@ def run(grid=N_GRID, cfg=None, no_fold=False, layout_out=None):
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
         layout_out = os.path.join(root, "gpurun_out", "pmc_layout.json")
     with open(layout_out, "w") as f:
-        json.dump({"slots": slots, "value_blocks": vblocks, "descriptor_bytes": meta, "kernel": A.level_kernel(0), "grid": grid}, f)
+        json.dump({"slots": slots, "value_blocks": vblocks, "descriptor_bytes": meta, "kernel": A.level_kernel(0), "grid": grid,
+                   "nrow": len(rp) - 1, "nnz": int(rp[-1]), "stored_entries": A.level_format(0)[1]}, f)
 
 
 def collect(d):
@@ -88,6 +92,16 @@ def summarize(fetch_dir, write_dir, out_path, grid=N_GRID, layout_path=None, qui
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lay_path = layout_path or os.path.join(root, "gpurun_out", "pmc_layout.json")
     layout = json.load(open(lay_path)) if os.path.exists(lay_path) else None
+    if layout and layout.get("nrow"):  # the matrix the --run pass actually used (e.g. the unstructured stand-in)
+        n, nnz = layout["nrow"], layout["nnz"]
+        known_read = {"axpby": 16 * n, "dot": 16 * n, "copy_int": 4 * n}
+        known_write = {"axpby": 8 * n, "dot": 0, "copy_int": 4 * n}
+        f8 = known_read["axpby"] / fetch["axpby"]
+        f8b = known_read["dot"] / fetch["dot"]
+        f4 = known_read["copy_int"] / fetch["copy_int"]
+        wf8 = known_write["axpby"] / write["axpby"]
+        wf4 = known_write["copy_int"] / write["copy_int"]
+        pad_nnz = layout.get("stored_entries", nnz)
     kind = int(fetch.pop("_kind", 2.0))
     cnt.pop("_kind", None)
     bytes4 = (4 * pad_nnz + 4 * n) if kind == 2 else ((4 * nnz + 4 * n) if kind == 0 else 0)
@@ -132,8 +146,9 @@ if __name__ == "__main__":
     ap.add_argument("--kcfg", default=None, help="kind,vec,nt,remap")
     ap.add_argument("--no-fold", action="store_true")
     ap.add_argument("--layout", default=None, help="where --run writes / --summarize reads the layout description")
+    ap.add_argument("--fem", type=int, default=0, help="--run on the unstructured P1-FEM stand-in with this many points instead of the grid")
     a = ap.parse_args()
     if a.run:
-        run(a.grid, a.kcfg, a.no_fold, a.layout)
+        run(a.grid, a.kcfg, a.no_fold, a.layout, a.fem)
     elif a.summarize:
         summarize(a.summarize[0], a.summarize[1], a.out, a.grid, a.layout)

@@ -37,3 +37,29 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def runs(path, needle="sdia_tab_kernel<2, false, 1>"):
+    """Durations of the finest-level sweep kernel by position inside a run of consecutive launches of it."""
+    rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
+    pos, bypos, gaps = 0, collections.defaultdict(list), collections.defaultdict(list)
+    prev_end = None
+    for r in rows:
+        if needle in r["Kernel_Name"]:
+            d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+            bypos[pos].append(d)
+            if prev_end is not None:
+                gaps[pos].append((int(r["Start_Timestamp"]) - prev_end) * 1e-3)
+            pos += 1
+        else:
+            pos = 0
+        prev_end = int(r["End_Timestamp"])
+    print(f"position-in-run statistics of {needle}:")
+    for p in sorted(bypos):
+        v = sorted(bypos[p])
+        g = sorted(gaps[p]) or [0.0]
+        print(f"  pos {p}: n={len(v):5d} median {v[len(v) // 2]:7.2f} us  min {v[0]:7.2f}  max {v[-1]:7.2f}   gap before (median) {g[len(g) // 2]:6.2f} us")
+
+
+if __name__ == "__main__" and len(sys.argv) > 3 and sys.argv[3] == "runs":
+    runs(sys.argv[1], sys.argv[4] if len(sys.argv) > 4 else "sdia_tab_kernel<2, false, 1>")
