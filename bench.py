@@ -99,6 +99,27 @@ def main():
         dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist = dist_mod
 
+    # Multi-GPU insurance: the partitioned path (RCCL halo exchange) cannot be exercised with N >= 2 on the one-GPU boxes this
+    # repo is developed on, so the whole multi-rank run sits under a watchdog.  A hang (a defect to diagnose from the log, not a
+    # measurement) ends with ONE record that says so and a non-zero exit code instead of blocking the launcher forever.
+    dist_dog = None
+    emitted = [False]
+    if world > 1:
+        def dist_bail():
+            msg = f"multi-GPU run did not finish within {dist_timeout:.0f} s on rank {rank} (hang in the partitioned solver or its transport)"
+            log(msg)
+            if rank == 0 and not emitted[0]:
+                rec = {"metric": "AMG-PCG solve iterations/sec (7-pt 3D Poisson, fp64) + HBM GB/s", "value": 0.0, "unit": "iterations/s", "n_gpus": world,
+                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                       "dtype": "f64", "data": "synthetic", "failed": True, "config": {"workload": f"7-pt 3D Poisson CSR {args.grid}^3", "failure": msg}}
+                os.write(json_fd, (json.dumps(rec) + "\n").encode())
+            os._exit(5)
+
+        dist_timeout = float(os.environ.get("SPARSH_BENCH_DIST_TIMEOUT", "900"))
+        dist_dog = threading.Timer(dist_timeout, dist_bail)
+        dist_dog.daemon = True
+        dist_dog.start()
+
     import sparsh_amg_amd as sa
     from sparsh_amg_amd import problems
 
@@ -561,6 +582,7 @@ def main():
     def emit():
         if rank == 0 and not printed.is_set():
             printed.set()
+            emitted[0] = True
             sys.stdout.flush()
             os.write(json_fd, (json.dumps(line) + "\n").encode())
 
@@ -624,6 +646,8 @@ def main():
             line["config"]["overlap_phase"] = {"error": repr(e), "adopted": False}
         dog.cancel()
     emit()
+    if dist_dog is not None:
+        dist_dog.cancel()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
