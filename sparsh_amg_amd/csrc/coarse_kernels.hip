@@ -255,7 +255,11 @@ __global__ __launch_bounds__(kCB) void bt_solve_kernel(BtStep s, int mode, int f
             const double bg = mode == 0 ? b[perm[g]] : 0.0;
             double acc = 0.0;
 #pragma unroll 4
-            for (int k = 0; k < ell_k; ++k) acc += e_v[(size_t)k * n + g] * z[e_ci[(size_t)k * n + g]];
+            for (int k = 0; k < ell_k; ++k) {
+                const double ev = e_v[(size_t)k * n + g];
+                const double zv = z[e_ci[(size_t)k * n + g]];
+                acc += ev != 0.0 ? ev * zv : 0.0;  // padding must not pick up a NaN a broken-down solve left in z
+            }
             w[r] = mode == 0 ? bg - acc : acc;
         }
     } else {

@@ -6,7 +6,7 @@ tests/test_gpu_configs.py; this prints their rates for DESIGN.md / profiles/):
   CU   unstructured P1-FEM M + dt K stand-in, 525 825 rows: AMG-PBiCGStab iterations/s
 SPARSH_MTX=/path/to/file.mtx adds that MatrixMarket file as a further CU case.
 All rates are solve-phase only (hierarchy resident, vectors in HBM), full solves to 1e-8.
-Usage: python tools/config_bench.py > profiles/r01_configs.json"""
+Usage: python tools/config_bench.py > profiles/r02_configs.json"""
 import json
 import os
 import sys
@@ -19,14 +19,19 @@ import sparsh_amg_amd as sa
 from sparsh_amg_amd import problems
 
 
-def run(name, rp, ci, v, methods, **params):
+def run(name, rp, ci, v, methods, rhs="ones", **params):
     n = len(rp) - 1
     out = {"rows": n, "nnz": int(rp[-1])}
     A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, print_solve=0, **params))
     out["levels"] = [A.level_info(l)["nrow"] for l in range(A.nlevels)]
     out["level_kernels"] = [A.level_kernel(l) for l in range(A.nlevels - 1)]
-    out["setup_seconds_host"] = round(A.setup_seconds, 3)
-    b = np.ones(n)
+    out["coarsest"] = A.coarse_info()
+    out["coarse_solve_us"] = round(A.bench_op("coarse", A.nlevels - 1, 20) * 1e6, 1)
+    out["setup_seconds"] = round(A.setup_seconds, 3)
+    out["rhs"] = rhs
+    # constant right-hand side for the Poisson cases (the reference's goldens use b = 1); the FEM stand-in gets a random
+    # one: on M + dt K the constant vector is almost an eigenvector and BiCGStab breaks down on it (tests/test_gpu_configs.py)
+    b = np.ones(n) if rhs == "ones" else np.random.default_rng(4).standard_normal(n) * 1e-3
     bd, xd = A.dev_alloc(8 * n), A.dev_alloc(8 * n)
     A.h2d(bd, b)
     for m in methods:
@@ -55,8 +60,12 @@ def run(name, rp, ci, v, methods, **params):
 
 def main():
     res = {}
-    res["C2D_poisson2d_1000"] = run("C2D", *problems.poisson2d(1000), ["amg", "pcg"])
+    res["C2D_poisson2d_1000"] = run("C2D", *problems.poisson2d(1000), ["amg", "pcg"])  # default: the reference's 6 levels + block-tridiagonal direct solve
+    res["C2D_poisson2d_1000_extended_hierarchy"] = run("C2D ext", *problems.poisson2d(1000), ["amg", "pcg"], coarse_limit=8192)
+    res["C3D_poisson3d_100"] = run("100^3", *problems.poisson3d(100), ["amg", "pcg"])
+    res["C3D_poisson3d_100_extended_hierarchy"] = run("100^3 ext", *problems.poisson3d(100), ["amg", "pcg"], coarse_limit=8192)
     res["C3D_poisson3d_216"] = run("C3D", *problems.poisson3d(216), ["amg", "pcg"])
+    res["C3D_poisson3d_216_10_levels_block_tridiagonal"] = run("C3D 10 levels", *problems.poisson3d(216), ["amg", "pcg"], max_levels=10, coarse_limit=1 << 30)
     # nu = 6 sweeps: what the reference's GPU path effectively runs (smooth_iter without the +1 of the CPU path)
     res["C3D_poisson3d_216_nu6"] = run("C3D nu=6", *problems.poisson3d(216), ["amg", "pcg"], sweeps=6)
     # Beck's classical C/F interpolation instead of HEM aggregation (general multi-entry P and R, denser
@@ -67,8 +76,8 @@ def main():
     mtx = os.environ.get("SPARSH_MTX")  # e.g. SuiteSparse parabolic_fem.mtx when it is on the box
     if mtx and os.path.exists(mtx):
         res["CU_" + os.path.basename(mtx)] = run("CU file", *problems.read_matrix_market(mtx), ["pbicg", "pcg"])
-    res["CU_fem_unstructured_525825"] = run("CU", *problems.fem_unstructured(), ["pbicg", "pcg"])
-    res["CU_fem_unstructured_60000"] = run("CU60k", *problems.fem_unstructured(60000, seed=7), ["pbicg", "pcg"])
+    res["CU_fem_unstructured_525825"] = run("CU", *problems.fem_unstructured(), ["pbicg", "pcg"], rhs="random")
+    res["CU_fem_unstructured_60000"] = run("CU60k", *problems.fem_unstructured(60000, seed=7), ["pbicg", "pcg"], rhs="random")
     print(json.dumps(res, indent=1))
 
 

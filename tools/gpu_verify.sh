@@ -13,9 +13,9 @@ python tools/kernel_bench.py --levels 13 > gpurun_out/kb_final.txt 2>&1 || exit 
 python tools/config_bench.py > gpurun_out/configs.json 2> gpurun_out/configs.err || exit 9
 cd /tmp
 rm -rf $R/gpurun_out/prof_stats $R/gpurun_out/pmc_run
-SPARSH_BENCH_NO_CPU=1 SPARSH_BENCH_NO_GENERAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python3 $R/bench.py > $R/gpurun_out/prof_stats_bench.json 2> $R/gpurun_out/prof_stats.err || exit 5
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_run/fetch -- python3 $R/tools/pmc_traffic.py --run > $R/gpurun_out/pmc_fetch.log 2>&1 || exit 6
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_run/write -- python3 $R/tools/pmc_traffic.py --run > $R/gpurun_out/pmc_write.log 2>&1 || exit 7
+# the same bench command under the kernel tracer (no counter passes / family runs / CPU leg inside a traced process)
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python3 $R/bench.py --no-cpu --no-pmc --no-families > $R/gpurun_out/prof_stats_bench.json 2> $R/gpurun_out/prof_stats.err || exit 5
 cd $R
-python3 tools/pmc_traffic.py --summarize gpurun_out/pmc_run/fetch gpurun_out/pmc_run/write --out gpurun_out/pmc_latest.json > gpurun_out/pmc_summary.txt 2>&1 || exit 8
+find gpurun_out/prof_stats -name "*kernel_trace.csv" -size +4M -delete   # the per-dispatch trace is large; the stats summary is what is kept
+# (HBM traffic of the dominant kernel is measured by bench.py itself: gpurun_out/pmc_bench_run.json)
 tail -2 gpurun_out/gpu_tests.log; tail -1 gpurun_out/smoke.log
