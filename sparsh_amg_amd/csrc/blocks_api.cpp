@@ -75,9 +75,8 @@ struct Mirror {
         D.rowptr = up(H.rowptr, (size_t)H.nrow + 1);
         D.col = up(H.col, (size_t)D.nnz, kCsrPad);
         D.val = up(H.val, (size_t)D.nnz, kCsrPad);
-        std::vector<int> rb((size_t)H.nrow + 2);
-        D.nblk = build_rowblocks(H.nrow, H.rowptr, rb.data());
-        D.rowblk = up(rb.data(), (size_t)D.nblk + 1);
+        const std::vector<int> rec = rowblock_records(H.nrow, H.rowptr, &D.nblk);
+        D.rowblk = up(rec.data(), rec.size());
     }
 };
 

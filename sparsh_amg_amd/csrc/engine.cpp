@@ -377,8 +377,10 @@ bool upload_csr(Engine &E, const HostCsr &A, DevCsr &D, bool with_sell)
     D.col = upload_padded(E, A.col, (size_t)D.nnz);
     D.val = upload_padded(E, A.val, (size_t)D.nnz);
     std::vector<int> rb((size_t)A.nrow + 2);
-    D.nblk = build_rowblocks(A.nrow, A.rowptr, rb.data());
-    D.rowblk = upload(E, rb.data(), (size_t)D.nblk + 1);
+    {
+        const std::vector<int> rec = rowblock_records(A.nrow, A.rowptr, &D.nblk);
+        D.rowblk = upload(E, rec.data(), rec.size());
+    }
     D.nwblk = build_waveblocks(A.nrow, A.rowptr, rb.data());
     D.waveblk = upload(E, rb.data(), (size_t)D.nwblk + 1);
     if (with_sell && !upload_sell(E, A, D)) {
@@ -842,7 +844,7 @@ double Engine::op_resnorm(int l, const double *b, const double *x)
     return read_scalar(S_RES);
 }
 
-void Engine::op_restrict(int l, const double *r, double *bc)
+bool Engine::op_restrict(int l, const double *r, double *bc, bool fuse_zero)
 {
     DevLevel &L = lev_[l];
     halo(L.planR, const_cast<double *>(r));
@@ -850,11 +852,18 @@ void Engine::op_restrict(int l, const double *r, double *bc)
     a.x = r;
     const bool gather = dist_ && !L.replicated && lev_[l + 1].replicated;
     a.y = gather ? bc + gather_part_.lo(comm_->rank) : bc;  // my share of the replicated level's rhs
-    if (L.P_is_aggregation)
+    bool fused = false;
+    if (L.P_is_aggregation && fuse_zero && !gather && l + 2 < (int)lev_.size() && lev_[l + 1].n == L.R.nrow) {
+        // the coarse level's first pre-sweep from a zero guess rides along (one launch less per level)
+        launch_restrict_agg_zero(L.R.nrow, L.R.rowptr, L.R.col, r, a.y, lev_[l + 1].diag, prm_.omega, lev_[l + 1].x, st_);
+        fused = true;
+    } else if (L.P_is_aggregation) {
         launch_restrict_agg(L.R.nrow, L.R.rowptr, L.R.col, r, a.y, st_);
-    else
+    } else {
         launch_csr(L.R, OP_SPMV, a, false, st_, cfg_);
+    }
     if (gather) note_comm(comm_->allgather(bc, gather_part_, st_), "allgather");
+    return fused;
 }
 
 void Engine::op_prolong(int l, const double *xc, double *xf)
@@ -883,12 +892,12 @@ double Engine::op_dot(int n, const double *x, const double *y)
 
 // `sweeps` fused Jacobi sweeps on level buffers; the current iterate is L.x on entry and exit
 // (the ping-pong partner L.x2 is scratch).  parallel::jacobi_smoother, src/AMG_smoothers.cpp:53-76.
-void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, double *dot_partial, int *dot_nblk)
+void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, double *dot_partial, int *dot_nblk, bool zero_done)
 {
     int k = 0;
     bool dot_done = false;
     if (x_zero && sweeps > 0) {
-        launch_jacobi_zero(L.n, b, L.diag, prm_.omega, L.x, st_);
+        if (!zero_done) launch_jacobi_zero(L.n, b, L.diag, prm_.omega, L.x, st_);
         k = 1;
     }
     const bool timed = prof.enabled && &L == &lev_[0] && k < sweeps && prof.used + 2 <= prof.ev.size();
@@ -945,11 +954,12 @@ void Engine::vcycle(const double *b0, bool x0_zero, double *dot_partial, int *do
         if (dot_partial) launch_dot(lev_[0].n, lev_[0].x, b0, dot_partial, dot_nblk, st_);
         return;
     }
+    bool zero_done = false;  // the previous level's restriction already wrote this level's zero-guess sweep
     for (int l = 0; l < last; ++l) {
         DevLevel &L = lev_[l];
-        smooth(L, L.b, nu, l > 0 || x0_zero, nullptr, nullptr);  // coarse levels start from x = 0 (fill, :204)
-        op_residual(l, L.b, L.x, L.r);                           // store_residual
-        op_restrict(l, L.r, lev_[l + 1].b);                      // transfer_residual
+        smooth(L, L.b, nu, l > 0 || x0_zero, nullptr, nullptr, zero_done);  // coarse levels start from x = 0 (fill, :204)
+        op_residual(l, L.b, L.x, L.r);                                      // store_residual
+        zero_done = op_restrict(l, L.r, lev_[l + 1].b, nu > 0);             // transfer_residual (+ x_{l+1} = omega*b/d)
     }
     op_coarse(lev_[last].b, lev_[last].x);  // Direct_Solver_Pardiso_solve
     for (int l = last; l > 0; --l) {

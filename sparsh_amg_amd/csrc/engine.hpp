@@ -120,7 +120,8 @@ public:
     void op_jacobi(int l, const double *b, double *x, double *tmp, int sweeps, bool x_is_zero);  // result in x
     void op_residual(int l, const double *b, const double *x, double *r);
     double op_resnorm(int l, const double *b, const double *x);
-    void op_restrict(int l, const double *r, double *bc);
+    // fuse_zero: also write the coarse level's zero-guess sweep (aggregation P, no gather step); returns whether it did
+    bool op_restrict(int l, const double *r, double *bc, bool fuse_zero = false);
     void op_prolong(int l, const double *xc, double *xf);
     void op_coarse(const double *b, double *x);
     // z = V32(r): one application of the opt-in fp32 preconditioner (fp64 in/out); needs precond_fp32
@@ -149,7 +150,8 @@ private:
     // x0_zero: the initial guess of level 0 is zero (preconditioner use).
     // dot_partial: when non-null the last post-sweep also leaves partial sums of x.b there.
     void vcycle(const double *b0, bool x0_zero, double *dot_partial, int *dot_nblk);
-    void smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, double *dot_partial, int *dot_nblk);
+    // zero_done: the zero-guess sweep x = omega*b/d has already been written to L.x (fused into the restriction)
+    void smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, double *dot_partial, int *dot_nblk, bool zero_done = false);
     bool halo(const DevPlan &p, double *vec);  // pack + exchange (no-op on one GPU)
     // A_l-type operator on level L: exchanges the halo of a.x, then launches; with overlap enabled the
     // exchange runs on a second stream while the slices that touch no halo column are processed.

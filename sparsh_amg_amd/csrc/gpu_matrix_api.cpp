@@ -67,10 +67,10 @@ void sp_matrix_gpu::matrix_transfer_gpu(sp_matrix_mg &A, hipStream_t streams)
     D.rowptr = rowptr;
     D.col = colindex;
     D.val = val;
-    D.nblk = build_rowblocks(nrow, A.rowptr, rb.data());
+    const std::vector<int> rec = rowblock_records(nrow, A.rowptr, &D.nblk);
     if (D.rowblk) (void)hipFree(D.rowblk);
-    D.rowblk = dmalloc<int>((size_t)D.nblk + 1);
-    (void)hipMemcpy(D.rowblk, rb.data(), sizeof(int) * ((size_t)D.nblk + 1), hipMemcpyHostToDevice);
+    D.rowblk = dmalloc<int>(rec.size());
+    (void)hipMemcpy(D.rowblk, rec.data(), sizeof(int) * rec.size(), hipMemcpyHostToDevice);
     if (!g->partial) g->partial = dmalloc<double>((size_t)D.nblk + 8);
     if (!g->scal) g->scal = dmalloc<double>(S_COUNT);
     if (!g->pinned) (void)hipHostMalloc(reinterpret_cast<void **>(&g->pinned), 8 * sizeof(double), hipHostMallocDefault);

@@ -24,6 +24,9 @@
 
 #include "kernels.hpp"
 
+#include <algorithm>
+#include <vector>
+
 namespace sparsh {
 
 namespace {
@@ -260,9 +263,12 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(const int *__restrict
     const int bid = remap ? xcd_remap(blockIdx.x, nblk, remap) : blockIdx.x;
     if (bid >= nblk) return;  // whole workgroup leaves together
     const int tid = threadIdx.x;
-    const int r0 = rowblk[bid], r1 = rowblk[bid + 1];
+    // one 16-byte record per block {first row, end row, first entry, end entry}: the stream loads start one
+    // dependent round trip earlier than through rowblk -> rowptr
+    const int4 br = reinterpret_cast<const int4 *>(rowblk)[bid];
+    const int r0 = br.x, r1 = br.y;
     const int nrows = r1 - r0;
-    const int j0 = rowptr[r0], j1 = rowptr[r1];
+    const int j0 = br.z, j1 = br.w;
     const double *__restrict__ x = a.x;
 
     // row operands first: their latency hides under the product stream
@@ -1354,6 +1360,21 @@ __global__ __launch_bounds__(kBlock) void restrict_agg_kernel(int nc, const int 
     }
 }
 
+// the same restriction, fused with the zero-guess sweep of the coarse level it feeds: x_c = omega*b_c/d_c is what
+// jacobi_zero_kernel would compute from b_c in a launch of its own (same expression, bitwise the same values)
+__global__ __launch_bounds__(kBlock) void restrict_agg_zero_kernel(int nc, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                                    const double *__restrict__ r, double *__restrict__ bc,
+                                                                    const double *__restrict__ dc, double omega, double *__restrict__ xc)
+{
+    for (int J = blockIdx.x * kBlock + threadIdx.x; J < nc; J += gridDim.x * kBlock) {
+        const int j0 = rowptr[J], j1 = rowptr[J + 1];
+        double sum = 0.0;
+        for (int j = j0; j < j1; ++j) sum = sum + r[col[j]];
+        bc[J] = sum;
+        xc[J] = omega * sum / dc[J];
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void pack_kernel(int n, const int *__restrict__ idx, const double *__restrict__ vec,
                                                        double *__restrict__ out)
 {
@@ -1657,6 +1678,21 @@ int launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool finest, hipStre
     return 0;
 }
 
+std::vector<int> rowblock_records(int nrow, const int *rowptr, int *nblk)
+{
+    std::vector<int> rb((size_t)nrow + 2);
+    const int nb = build_rowblocks(nrow, rowptr, rb.data());
+    std::vector<int> rec((size_t)std::max(nb, 1) * 4, 0);
+    for (int k = 0; k < nb; ++k) {
+        rec[(size_t)4 * k] = rb[k];
+        rec[(size_t)4 * k + 1] = rb[k + 1];
+        rec[(size_t)4 * k + 2] = rowptr[rb[k]];
+        rec[(size_t)4 * k + 3] = rowptr[rb[k + 1]];
+    }
+    *nblk = nb;
+    return rec;
+}
+
 int build_waveblocks(int nrow, const int *rowptr, int *out)
 {
     int nb = 0;
@@ -1694,6 +1730,13 @@ void launch_restrict_agg(int nc, const int *rowptr, const int *col, const double
 {
     if (nc <= 0) return;
     hipLaunchKernelGGL(restrict_agg_kernel, dim3(ew_grid(nc)), dim3(kBlock), 0, st, nc, rowptr, col, r, bc);
+}
+
+void launch_restrict_agg_zero(int nc, const int *rowptr, const int *col, const double *r, double *bc, const double *dc, double omega,
+                              double *xc, hipStream_t st)
+{
+    if (nc <= 0) return;
+    hipLaunchKernelGGL(restrict_agg_zero_kernel, dim3(ew_grid(nc)), dim3(kBlock), 0, st, nc, rowptr, col, r, bc, dc, omega, xc);
 }
 
 void launch_gemv(int n, const double *M, const double *b, double *x, hipStream_t st)

@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <vector>
+
 namespace sparsh {
 
 // level-wide stencil of the sliced-diagonal layout (see DevCsr::sd_tab)
@@ -21,8 +23,8 @@ struct DevCsr {
     int *rowptr = nullptr;
     int *col = nullptr;
     double *val = nullptr;
-    // row blocks: block k owns rows [rowblk[k], rowblk[k+1]); nnz of a block <= kStreamNnz unless
-    // it is a single long row
+    // row blocks of the workgroup CSR-stream kernel: one record of 4 ints per block {first row, end row, first
+    // entry, end entry} (16-byte aligned); nnz of a block <= kStreamNnz unless it is a single long row
     int *rowblk = nullptr;
     int nblk = 0;
     // wave-granular schedule: wave-block k owns rows [waveblk[k], waveblk[k+1]) (<= 64 rows,
@@ -126,6 +128,8 @@ struct CsrArgs {
 // host-side builder of the row-block schedule (returns number of blocks; out sized nrow+1 max)
 int build_rowblocks(int nrow, const int *rowptr, int *out);
 int build_waveblocks(int nrow, const int *rowptr, int *out);
+// the row-block schedule as the 4-int records DevCsr::rowblk holds (4 * *nblk ints)
+std::vector<int> rowblock_records(int nrow, const int *rowptr, int *nblk);
 
 // returns the number of per-workgroup partial sums the launch writes (reducing ops)
 // `finest`: launch on the finest level (selects a separately named kernel instance for profilers)
@@ -142,6 +146,9 @@ void launch_jacobi_zero(int n, const double *b, const double *d, double omega, d
 void launch_prolong_agg(int n, const int *agg, const double *xc, double *xf, hipStream_t st);
 // bc[J] = sum of r over aggregate J (R = P^T of an aggregation P: all values 1.0, not read)
 void launch_restrict_agg(int nc, const int *rowptr, const int *col, const double *r, double *bc, hipStream_t st);
+// the same, and xc[J] = omega*bc[J]/dc[J]: the coarse level's zero-guess sweep in the same launch
+void launch_restrict_agg_zero(int nc, const int *rowptr, const int *col, const double *r, double *bc, const double *dc, double omega,
+                              double *xc, hipStream_t st);
 // x = A^{-1} b with the explicit row-major inverse (coarsest level)
 void launch_gemv(int n, const double *M, const double *b, double *x, hipStream_t st);
 
