@@ -163,6 +163,8 @@ def main():
             if dist is not None:
                 dist.broadcast_object_list(uid, src=0)
             A.comm_init_rccl(uid[0], rank, world)
+            if os.environ.get("SPARSH_BENCH_DEEP_HALO", "1") != "1":
+                A.set_deep_halo(False)
             log(f"setup ({host_threads} host threads, partitioned)")
             A.setup(prm)
             mode = "partitioned"
@@ -240,10 +242,12 @@ def main():
         A.profile(True)
     barrier()
     log("timed region")
+    ex0 = A.exchanges_issued()
     t0 = time.perf_counter()
     done = run_steps(args.steps)
     barrier()
     t1 = time.perf_counter()
+    exchanges_per_step = (A.exchanges_issued() - ex0) / max(1, args.steps)
     if not no_profile:
         A.profile(False)
     assert done == args.steps, (done, args.steps)
@@ -557,8 +561,10 @@ def main():
                                   "direct solve)" if coarse["extended"] else "the reference's own policy: level1 = 6 levels, the rest to the direct solver"),
                 "coarsest_level": coarse,
                 "parallelism": "1 GPU" if world == 1 else (mode_note or (
-                    f"{world} GPUs, one process each: contiguous row blocks on the {partitioned_levels} finest levels, halo exchange "
-                    f"(grouped ncclSend/ncclRecv) before every sweep/SpMV, 16-byte ncclAllReduce per fused scalar, coarser levels replicated")),
+                    f"{world} GPUs, one process each: contiguous row blocks on the {partitioned_levels} finest levels; deep-halo smoothing "
+                    f"(sweeps+1 ghost layers per block, ONE ghost-layer exchange per smoothing leg, grouped ncclSend/ncclRecv of packed "
+                    f"buffers: {exchanges_per_step:.1f} transport calls per iteration), 16-byte ncclAllReduce per fused scalar, coarser levels replicated")),
+                "transport_calls_per_iteration": round(exchanges_per_step, 2) if mode == "partitioned" else None,
                 "multi_gpu_parity": parity,
                 "algorithmic_GB_per_iteration": round(it_bytes / 1e9, 3),
                 "solve_GBps": round(it_bytes * its_per_s / 1e9, 1),
@@ -591,7 +597,10 @@ def main():
     # test transport, never on xGMI, so it runs under a watchdog: if it hangs, fails the parity
     # check against phase A, or is not faster, the phase-A record above is the one that is printed.
     force_b = os.environ.get("SPARSH_BENCH_FORCE_PHASE_B", "0") == "1"  # exercise this code path on one GPU
-    if mode == "partitioned" and (world > 1 or force_b) and os.environ.get("SPARSH_BENCH_TRY_OVERLAP", "1") == "1":
+    # Off by default since round 2: the partitioned levels run the deep-halo schedule (one exchange per smoothing leg), on
+    # which the overlap of a per-sweep exchange has nothing to act; SPARSH_BENCH_DEEP_HALO=0 SPARSH_BENCH_TRY_OVERLAP=1
+    # measures the per-sweep-exchange schedule with and without overlap instead.
+    if mode == "partitioned" and (world > 1 or force_b) and os.environ.get("SPARSH_BENCH_TRY_OVERLAP", "0") == "1":
         def bail():
             # a hang is a defect to diagnose, not a success: record it, print the phase-A measurement, exit non-zero
             log("overlap phase timed out (hang in the overlapped exchange schedule): reporting the non-overlapped measurement, exit code 4")

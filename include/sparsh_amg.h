@@ -261,6 +261,24 @@ int sparsh_local_range(sparsh_handle h, int level, int *lo, int *hi, int *replic
  * follow once the halo has landed.  Same arithmetic, same results.  May be toggled between solves. */
 int sparsh_set_overlap(sparsh_handle h, int enable);
 
+/* Deep-halo (communication-avoiding) smoothing on the partitioned levels, default ON; read by sparsh_setup.  Every rank
+ * holds, next to its own rows, K = sweeps + 1 layers of ghost rows of the level operator; a smoothing leg exchanges the
+ * ghost layers of its right-hand side and of its iterate ONCE and then sweeps a shrinking set of rows (sweep s updates the
+ * own rows and the layers <= K - s), so the own rows and the first ghost layer end up exactly as in the global sweep and
+ * the residual needs no exchange either: ~13 transport calls per AMG-PCG iteration instead of ~49 with three partitioned
+ * levels.  Same arithmetic per row (bitwise the one-rank results for a fixed number of cycles).  0 restores one halo
+ * exchange in front of every sweep (the overlap mode below applies to that schedule only).
+ * sparsh_exchanges_issued: transport calls (halo or ghost-layer exchanges) this handle has issued so far. */
+int sparsh_set_deep_halo(sparsh_handle h, int enable);
+/* Inspection / test hooks of a deep-halo level of this rank: info4 = {K (0: not a deep level), local rows (own + padding +
+ * ghost layers <= K-1), local columns (layers <= K), first ghost index}; layer_end(d) = local indices in layers 0..d;
+ * prefix_spmv: y[0, rows) = rows [0, rows) of the rank-local operator times x_ext (local columns), no exchange -- lets
+ * a test run every kernel family over every row prefix a smoothing leg launches. */
+int sparsh_deep_info(sparsh_handle h, int level, int *info4);
+int sparsh_deep_layer_end(sparsh_handle h, int level, int d, int *end);
+int sparsh_deep_prefix_spmv(sparsh_handle h, int level, int rows, const double *x_ext, double *y);
+long sparsh_exchanges_issued(sparsh_handle h);
+
 /* In-process transport for tests: nranks handles driven by nranks host threads on one GPU. */
 int sparsh_comm_group_create(int nranks, void **group);
 void sparsh_comm_group_destroy(void *group);

@@ -108,6 +108,11 @@ def _load():
         "sparsh_set_overlap": (C.c_int, [H, C.c_int]),
         "sparsh_comm_group_create": (C.c_int, [C.c_int, P(C.c_void_p)]),
         "sparsh_comm_group_destroy": (None, [C.c_void_p]),
+        "sparsh_set_deep_halo": (C.c_int, [H, C.c_int]),
+        "sparsh_deep_info": (C.c_int, [H, C.c_int, c_int_p]),
+        "sparsh_deep_layer_end": (C.c_int, [H, C.c_int, C.c_int, c_int_p]),
+        "sparsh_deep_prefix_spmv": (C.c_int, [H, C.c_int, C.c_int, c_dbl_p, c_dbl_p]),
+        "sparsh_exchanges_issued": (C.c_long, [H]),
         "sparsh_comm_group_fail_after": (C.c_int, [C.c_void_p, C.c_int]),
         "sparsh_comm_init_group": (C.c_int, [H, C.c_void_p, C.c_int]),
         "sparsh_dist_local_op": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p]),
@@ -339,6 +344,31 @@ class sp_matrix_mg:
         _check(lib.sparsh_coarse_info(self._h, info, C.byref(nbytes)))
         return {"rows": info[0], "dense": bool(info[1]), "block": info[2], "nblocks": info[3], "bandwidth": info[4],
                 "extended": bool(info[5]), "bytes": nbytes.value}
+
+    def set_deep_halo(self, enable=True):
+        """Deep-halo smoothing on partitioned levels (default on; call before setup)."""
+        _check(lib.sparsh_set_deep_halo(self._h, int(bool(enable))))
+        return self
+
+    def deep_info(self, level):
+        info = (C.c_int * 4)()
+        _check(lib.sparsh_deep_info(self._h, level, info))
+        d = {"K": info[0], "rows": info[1], "cols": info[2], "npad": info[3]}
+        d["layer_end"] = []
+        for q in range(d["K"] + 1 if d["K"] else 0):
+            e = C.c_int()
+            _check(lib.sparsh_deep_layer_end(self._h, level, q, C.byref(e)))
+            d["layer_end"].append(e.value)
+        return d
+
+    def deep_prefix_spmv(self, level, rows, x_ext):
+        x_ext = np.ascontiguousarray(x_ext, dtype=np.float64)
+        y = np.zeros(rows)
+        _check(lib.sparsh_deep_prefix_spmv(self._h, level, rows, _dp(x_ext), _dp(y)))
+        return y
+
+    def exchanges_issued(self):
+        return int(lib.sparsh_exchanges_issued(self._h))
 
     # -- multi-GPU -------------------------------------------------------------------------
     def comm_init_rccl(self, unique_id: bytes, rank: int, nranks: int):

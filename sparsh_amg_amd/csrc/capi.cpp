@@ -454,6 +454,50 @@ int sparsh_comm_init_group(sparsh_handle h, void *group, int rank)
     return SPARSH_OK;
 }
 
+int sparsh_deep_info(sparsh_handle h, int level, int *info4)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    const DevLevel &L = h->eng->level(level);
+    info4[0] = L.deep ? L.K : 0;
+    info4[1] = L.deep ? L.A.nrow : 0;
+    info4[2] = L.deep ? L.A.ncol : 0;
+    info4[3] = L.deep ? L.npad : 0;
+    return SPARSH_OK;
+}
+
+int sparsh_deep_layer_end(sparsh_handle h, int level, int d, int *end)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    const DevLevel &L = h->eng->level(level);
+    if (!L.deep || d < 0 || d > L.K) return fail(SPARSH_EINVAL, "not a deep-halo level / layer out of range");
+    *end = L.layer_end[d];
+    return SPARSH_OK;
+}
+
+int sparsh_deep_prefix_spmv(sparsh_handle h, int level, int rows, const double *x_ext, double *y)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    Engine &E = *h->eng;
+    const DevLevel &L = E.level(level);
+    if (!L.deep || rows < 0 || rows > L.A.nrow) return fail(SPARSH_EINVAL, "not a deep-halo level / bad prefix");
+    DBuf dx(E, (size_t)L.A.ncol, x_ext), dy(E, (size_t)L.A.nrow + 64);
+    if (!E.debug_prefix_spmv(level, rows, dx.p, dy.p)) return fail(SPARSH_ENODEV, E.error);
+    if (hipMemcpy(y, dy.p, (size_t)rows * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(SPARSH_ENODEV, "D2H failed");
+    return SPARSH_OK;
+}
+
+int sparsh_set_deep_halo(sparsh_handle h, int enable)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    h->eng->set_deep_halo(enable != 0);
+    return SPARSH_OK;
+}
+
+long sparsh_exchanges_issued(sparsh_handle h) { return (h && h->eng) ? h->eng->exchanges_issued() : 0; }
+
 int sparsh_set_overlap(sparsh_handle h, int enable)
 {
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");

@@ -16,6 +16,7 @@ namespace {
 class SelfComm : public Comm {
 public:
     bool exchange(const DevPlan &, double *, hipStream_t) override { return true; }
+    bool exchange_staged(const DevDeepPlan &, const double *, hipStream_t) override { return true; }
     bool allreduce_sum(double *, int, hipStream_t) override { return true; }
     bool allgather(double *, const Partition &, hipStream_t) override { return true; }
     bool barrier(hipStream_t) override { return true; }
@@ -52,6 +53,19 @@ public:
         }
         for (const HaloSeg &r : p.recv)
             if (good) good = ok(ncclRecv(vec + p.nloc + r.off, (size_t)r.cnt, ncclDouble, r.peer, comm, st), "ncclRecv");
+        const ncclResult_t e = ncclGroupEnd();
+        return good && ok(e, "ncclGroupEnd");
+    }
+    bool exchange_staged(const DevDeepPlan &p, const double *src, hipStream_t st) override
+    {
+        if (p.recv.empty() && p.send.empty()) return true;
+        if (p.nsend > 0) launch_pack(p.nsend, p.send_idx, src, p.sendbuf, st);
+        if (!ok(ncclGroupStart(), "ncclGroupStart")) return false;
+        bool good = true;
+        for (const HaloSeg &s : p.send)
+            if (good) good = ok(ncclSend(p.sendbuf + s.off, (size_t)s.cnt, ncclDouble, s.peer, comm, st), "ncclSend");
+        for (const HaloSeg &r : p.recv)
+            if (good) good = ok(ncclRecv(p.recvbuf + r.off, (size_t)r.cnt, ncclDouble, r.peer, comm, st), "ncclRecv");
         const ncclResult_t e = ncclGroupEnd();
         return good && ok(e, "ncclGroupEnd");
     }
@@ -123,6 +137,7 @@ struct ThreadGroup {
     int arrived = 0;
     long generation = 0;
     std::vector<const DevPlan *> plans;
+    std::vector<const DevDeepPlan *> dplans;
     std::vector<double *> vecs;
     std::vector<hipEvent_t> pub, done;  // per rank: "my boundary data is ready" / "my pulls are finished"
     std::vector<double *> ptrs;
@@ -147,6 +162,7 @@ ThreadGroup *thread_group_create(int nranks)
     ThreadGroup *g = new ThreadGroup();
     g->n = nranks;
     g->plans.assign((size_t)nranks, nullptr);
+    g->dplans.assign((size_t)nranks, nullptr);
     g->vecs.assign((size_t)nranks, nullptr);
     g->ptrs.assign((size_t)nranks, nullptr);
     g->pub.assign((size_t)nranks, nullptr);
@@ -225,6 +241,47 @@ public:
         return okp;
     }
     bool primed = false;
+    // same stream-asynchronous pull protocol for the staged (deep-halo) exchange: peers read my sendbuf
+    bool exchange_staged(const DevDeepPlan &p, const double *src, hipStream_t st) override
+    {
+        if (g->fail_after >= 0 && calls++ >= g->fail_after) {
+            error = "injected transport failure (test hook)";
+            return false;
+        }
+        if (!g->pub[rank]) {
+            (void)hipEventCreateWithFlags(&g->pub[rank], hipEventDisableTiming);
+            (void)hipEventCreateWithFlags(&g->done[rank], hipEventDisableTiming);
+        }
+        g->wait();  // peers may still be pulling the previous exchange's data out of my sendbuf
+        if (primed)
+            for (int r = 0; r < size; ++r)
+                if (r != rank && g->done[r]) (void)hipStreamWaitEvent(st, g->done[r], 0);
+        if (p.nsend > 0) launch_pack(p.nsend, p.send_idx, src, p.sendbuf, st);
+        (void)hipEventRecord(g->pub[rank], st);
+        g->dplans[rank] = &p;
+        g->wait();
+        bool okp = true;
+        for (const HaloSeg &r : p.recv) {
+            const DevDeepPlan *q = g->dplans[r.peer];
+            const HaloSeg *sseg = nullptr;
+            if (q)
+                for (const HaloSeg &s : q->send)
+                    if (s.peer == rank) sseg = &s;
+            if (!sseg || sseg->cnt != r.cnt) {
+                error = "thread comm: staged send/recv plans disagree";
+                okp = false;
+                continue;
+            }
+            (void)hipStreamWaitEvent(st, g->pub[r.peer], 0);
+            (void)hipMemcpyAsync(p.recvbuf + r.off, q->sendbuf + sseg->off, (size_t)r.cnt * sizeof(double), hipMemcpyDeviceToDevice, st);
+        }
+        (void)hipEventRecord(g->done[rank], st);
+        g->wait();
+        for (const HaloSeg &s : p.send)
+            if (g->done[s.peer]) (void)hipStreamWaitEvent(st, g->done[s.peer], 0);
+        primed = true;
+        return okp;
+    }
     bool allreduce_sum(double *dev, int n, hipStream_t st) override
     {
         std::vector<double> &mine = g->host[rank];

@@ -24,6 +24,17 @@ struct DevPlan {
     bool empty() const { return nhalo == 0 && nsend == 0; }
 };
 
+// device-side image of a DeepPlan (dist.hpp): ghost layers travel through staging buffers, one contiguous
+// segment per peer each way; the caller scatters recvbuf to the ghost positions afterwards
+struct DevDeepPlan {
+    int depth = 0, nrecv = 0, nsend = 0;
+    std::vector<HaloSeg> recv, send;   // off / cnt into recvbuf / sendbuf
+    int *send_idx = nullptr;           // device, nsend: own local indices to pack
+    int *recv_pos = nullptr;           // device, nrecv: local index of every staged entry
+    double *sendbuf = nullptr, *recvbuf = nullptr;
+    bool empty() const { return nrecv == 0 && nsend == 0; }
+};
+
 class Comm {
 public:
     virtual ~Comm() = default;
@@ -34,6 +45,9 @@ public:
     // When the work queued on st up to here has completed, this rank's halo has landed AND every
     // peer has finished reading this rank's boundary entries (send + receive semantics).
     virtual bool exchange(const DevPlan &p, double *vec, hipStream_t st) = 0;
+    // deep-halo exchange: packs src[send_idx] into sendbuf and moves every peer's segment into this rank's recvbuf
+    // (same completion semantics as exchange()).  The caller unpacks recvbuf.
+    virtual bool exchange_staged(const DevDeepPlan &p, const double *src, hipStream_t st) = 0;
     // in-place sum over ranks of n doubles in device memory
     virtual bool allreduce_sum(double *dev, int n, hipStream_t st) = 0;
     // every rank contributes full[lo(rank) .. hi(rank)) of `part`; afterwards all ranks hold all of it

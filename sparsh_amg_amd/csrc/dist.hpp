@@ -62,4 +62,42 @@ struct LocalOp {
 };
 LocalOp extract_local(const HostCsr &M, const Partition &rowsP, const Partition &colsP, int rank);
 
+// ---- deep halo (communication-avoiding smoothing) -------------------------------------------------
+// A rank that knows its input vector on its own rows and on the K layers of rows around them (layer d = rows at
+// graph distance d from the own block, through the columns of A) can run K-1 Jacobi sweeps without talking to
+// anybody: sweep s updates its own rows and the layers <= K-s, reading layers <= K-s+1 of the previous iterate.
+// After nu sweeps with K = nu+1 the own rows AND layer 1 hold exactly what the global sweep would have produced,
+// so the residual that follows needs no exchange either.  One exchange per smoothing leg instead of one per sweep.
+//
+// Local numbering: [own rows | padding up to a multiple of 64 | layer 1 | ... | layer K], ascending global index
+// inside a layer (the padding rows are empty: a launch over the "own" slices never touches a ghost row).  The
+// local operator has the rows of layers 0..K-1 (layer K is referenced, never updated); entry order inside every
+// row is the global one, so row sums stay bitwise identical to the one-rank operator.
+struct DeepPlan {  // exchange of the ghost layers <= depth of one vector
+    int depth = 0;
+    int nrecv = 0;                 // ghost entries received (= layer_end[depth] - nloc)
+    std::vector<HaloSeg> recv;     // per peer: off / cnt into the receive staging buffer
+    std::vector<int> recv_pos;     // staging entry k belongs at local index recv_pos[k]
+    std::vector<HaloSeg> send;     // per peer: off / cnt into send_idx
+    std::vector<int> send_idx;     // own local indices to pack
+};
+
+struct DeepLocal {
+    int K = 0;
+    int nloc = 0;                  // own rows
+    int npad = 0;                  // own rows rounded up to a multiple of 64 = local index of the first ghost
+    HostCsr M;                     // rows of layers 0..K-1, columns of layers 0..K (local numbering)
+    std::vector<int> layer_end;    // layer_end[d] = number of local indices in layers 0..d (d = 0..K); layer_end[0] = npad
+    std::vector<int> global_of;    // global index of every local index (own, -1 for padding, all ghost layers)
+    std::vector<DeepPlan> plans;   // one per requested depth
+    const DeepPlan *plan(int depth) const
+    {
+        for (const DeepPlan &p : plans)
+            if (p.depth == depth) return &p;
+        return nullptr;
+    }
+};
+// A: square level operator, P: its row partition.  depths: which exchange plans to build (each <= K).
+DeepLocal extract_local_deep(const HostCsr &A, const Partition &P, int rank, int K, const std::vector<int> &depths);
+
 }  // namespace sparsh

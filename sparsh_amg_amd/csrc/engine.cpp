@@ -170,7 +170,7 @@ bool upload_sdia(Engine &E, const HostCsr &A, DevCsr &D)
         const int r1 = std::min(n, (s + 1) * 64);
         for (int r = s * 64; r < r1; ++r) {
             for (int j = A.rowptr[r]; j < A.rowptr[r + 1]; ++j) {
-                slots.emplace_back(gcol[j] - (A.grow0 + r), A.col[j] - r);
+                slots.emplace_back(gcol[j] - A.grow(r), A.col[j] - r);
                 if (j > A.rowptr[r] && gcol[j] <= gcol[j - 1]) sorted = false;  // unsorted / duplicate columns
             }
         }
@@ -209,7 +209,7 @@ bool upload_sdia(Engine &E, const HostCsr &A, DevCsr &D)
         for (int r = s * 64; r < r1; ++r) {
             const int lane = r & 63;
             for (int j = A.rowptr[r]; j < A.rowptr[r + 1]; ++j) {
-                const Slot key(gcol[j] - (A.grow0 + r), A.col[j] - r);
+                const Slot key(gcol[j] - A.grow(r), A.col[j] - r);
                 const int d = (int)(std::lower_bound(slots.begin(), slots.end(), key) - slots.begin());
                 mask[(size_t)base + d] |= 1ull << lane;
                 val[((size_t)base + d) * 64 + lane] = A.val[j];
@@ -339,12 +339,17 @@ bool upload_sdia(Engine &E, const HostCsr &A, DevCsr &D)
                 if (r[40] <= 0) continue;
                 bool ok = true;
                 unsigned long long mm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                int last_hit = -1;
                 for (int q = 0; q < r[40] && ok; ++q) {
                     int hit = -1;
                     for (int u = 0; u < tab.nd; ++u)
                         if (tab.off[u] == r[q] && std::memcmp(&tab.cval[u], &r[24 + 2 * q], 8) == 0) hit = u;
-                    if (hit < 0) ok = false;
+                    // the slice's slots are stored in each row's entry order (global column order); the table kernel adds
+                    // in table order, so the two orders must agree.  They can differ on ghost rows of a deep-halo block,
+                    // whose neighbours in other layers sit at local offsets of the opposite sign (+plane <-> -plane).
+                    if (hit <= last_hit) ok = false;
                     else std::memcpy(&mm[hit], &r[8 + 2 * q], 8);
+                    last_hit = hit;
                 }
                 if (!ok) continue;
                 for (int u = 0; u < 8; ++u) tmask[(size_t)sl * 8 + u] = mm[u];
@@ -368,7 +373,11 @@ bool upload_sdia(Engine &E, const HostCsr &A, DevCsr &D)
     return D.sd_ptr && D.sd_off && D.sd_mask && D.sd_vidx && D.sd_cval && D.sd_val;
 }
 
-bool upload_csr(Engine &E, const HostCsr &A, DevCsr &D, bool with_sell)
+// cuts: row indices at which a row block / wave block must end (deep-halo operators: launches over a prefix of
+// the rows -- own rows, own rows + some ghost layers -- must not spill into the next segment); blk_first /
+// wblk_first receive the first row of every block for the prefix look-up
+bool upload_csr(Engine &E, const HostCsr &A, DevCsr &D, bool with_sell, const std::vector<int> *cuts = nullptr,
+                std::vector<int> *blk_first = nullptr, std::vector<int> *wblk_first = nullptr)
 {
     D.nrow = A.nrow;
     D.ncol = A.ncol;
@@ -377,12 +386,41 @@ bool upload_csr(Engine &E, const HostCsr &A, DevCsr &D, bool with_sell)
     D.col = upload_padded(E, A.col, (size_t)D.nnz);
     D.val = upload_padded(E, A.val, (size_t)D.nnz);
     std::vector<int> rb((size_t)A.nrow + 2);
-    {
+    if (!cuts) {
         const std::vector<int> rec = rowblock_records(A.nrow, A.rowptr, &D.nblk);
         D.rowblk = upload(E, rec.data(), rec.size());
+        D.nwblk = build_waveblocks(A.nrow, A.rowptr, rb.data());
+        D.waveblk = upload(E, rb.data(), (size_t)D.nwblk + 1);
+    } else {
+        // schedules built segment by segment: no block straddles a cut
+        std::vector<int> rec, wb(1, 0);
+        int seg0 = 0;
+        std::vector<int> ends(*cuts);
+        ends.push_back(A.nrow);
+        for (int seg1 : ends) {
+            if (seg1 <= seg0) continue;
+            int nb = 0;
+            const std::vector<int> r = rowblock_records(seg1 - seg0, A.rowptr + seg0, &nb);
+            for (int k = 0; k < nb; ++k) {
+                rec.push_back(r[(size_t)4 * k] + seg0);
+                rec.push_back(r[(size_t)4 * k + 1] + seg0);
+                rec.push_back(r[(size_t)4 * k + 2]);
+                rec.push_back(r[(size_t)4 * k + 3]);
+                if (blk_first) blk_first->push_back(r[(size_t)4 * k] + seg0);
+            }
+            const int nw = build_waveblocks(seg1 - seg0, A.rowptr + seg0, rb.data());
+            for (int k = 0; k < nw; ++k) {
+                if (wblk_first) wblk_first->push_back(rb[k] + seg0);
+                wb.push_back(rb[k + 1] + seg0);
+            }
+            seg0 = seg1;
+        }
+        D.nblk = (int)(rec.size() / 4);
+        if (rec.empty()) rec.assign(4, 0);
+        D.rowblk = upload(E, rec.data(), rec.size());
+        D.nwblk = (int)wb.size() - 1;
+        D.waveblk = upload(E, wb.data(), wb.size());
     }
-    D.nwblk = build_waveblocks(A.nrow, A.rowptr, rb.data());
-    D.waveblk = upload(E, rb.data(), (size_t)D.nwblk + 1);
     if (with_sell && !upload_sell(E, A, D)) {
         if (E.error.empty()) E.error = "building the sliced-ELL mirror failed";
         return false;
@@ -440,6 +478,59 @@ bool Engine::upload_plan(const HaloPlan &h, DevPlan &d)
         if (!d.send_idx || !d.sendbuf) return false;
     }
     return true;
+}
+
+bool Engine::upload_deep_plan(const DeepPlan &h, DevDeepPlan &d)
+{
+    d.depth = h.depth;
+    d.nrecv = h.nrecv;
+    d.nsend = (int)h.send_idx.size();
+    d.recv = h.recv;
+    d.send = h.send;
+    if (d.nsend > 0) {
+        d.send_idx = upload(*this, h.send_idx.data(), h.send_idx.size());
+        d.sendbuf = static_cast<double *>(dalloc((size_t)d.nsend * 8));
+        if (!d.send_idx || !d.sendbuf) return false;
+    }
+    if (d.nrecv > 0) {
+        d.recv_pos = upload(*this, h.recv_pos.data(), h.recv_pos.size());
+        d.recvbuf = static_cast<double *>(dalloc((size_t)d.nrecv * 8));
+        if (!d.recv_pos || !d.recvbuf) return false;
+    }
+    return true;
+}
+
+bool Engine::deep_exchange(DevLevel &L, int which, double *vec)
+{
+    const DevDeepPlan &p = L.dplan[which];
+    if (p.depth <= 0) return true;
+    ++n_exchanges_;
+    if (!note_comm(comm_->exchange_staged(p, vec, st_), "deep-halo exchange")) return false;
+    launch_unpack(p.nrecv, p.recv_pos, p.recvbuf, vec, st_);
+    return true;
+}
+
+// A deep level's operator restricted to its first `rows` local rows (own rows, or own rows + the ghost layers a
+// sweep still has to update).  Whole slices / row blocks are launched: rows past the prefix inside the last one
+// produce values nobody reads.
+int Engine::launch_prefix(DevLevel &L, int rows, CsrOp op, const CsrArgs &a)
+{
+    DevCsr V = L.A;
+    rows = std::min(rows, L.A.nrow);
+    V.nrow = rows;  // exact: the sliced kernels mask the rows past it, the block schedules are cut at every prefix end
+    if (V.nslice > 0) V.nslice = (rows + 63) / 64;
+    V.nblk = (int)(std::lower_bound(L.blk_first.begin(), L.blk_first.end(), rows) - L.blk_first.begin());
+    V.nwblk = (int)(std::lower_bound(L.wblk_first.begin(), L.wblk_first.end(), rows) - L.wblk_first.begin());
+    return launch_csr(V, op, a, L.fine, st_, cfg_);
+}
+
+bool Engine::debug_prefix_spmv(int l, int rows, const double *x_ext, double *y)
+{
+    CsrArgs a;
+    a.x = x_ext;
+    a.y = y;
+    launch_prefix(lev_[l], rows, OP_SPMV, a);
+    return check(hipStreamSynchronize(st_), "sync");
 }
 
 int Engine::setup(const sparsh_params &p)
@@ -512,6 +603,27 @@ int Engine::setup(const sparsh_params &p)
         } else {
             const Partition &pl = parts_[l];
             d.n = pl.hi(me) - pl.lo(me);
+            d.deep = deep_halo_ && prm_.sweeps >= 1 && !prm_.precond_fp32;
+            if (d.deep) {
+                // deep-halo layout: own rows + K = sweeps + 1 ghost layers; exchange plans of depth 1 (SpMV-type
+                // calls outside a smoothing leg), K-1 (right-hand side of a leg) and K (iterate of a leg)
+                d.K = prm_.sweeps + 1;
+                DeepLocal dl = extract_local_deep(h.A, pl, me, d.K, {1, d.K - 1, d.K});
+                d.npad = dl.npad;
+                d.layer_end = dl.layer_end;
+                {
+                    std::vector<int> cuts;  // own rows | padding | layer 1 | ... : prefix launches end exactly there
+                    cuts.push_back(d.n);
+                    for (int q = 0; q + 1 < d.K; ++q) cuts.push_back(dl.layer_end[q]);
+                    if (!upload_csr(*this, dl.M, d.A, true, &cuts, &d.blk_first, &d.wblk_first)) return SPARSH_ENODEV;
+                }
+                for (int q = 0; q < 3; ++q)
+                    if (!upload_deep_plan(dl.plans[q], d.dplan[q])) return SPARSH_ENODEV;
+                std::vector<double> dg((size_t)dl.M.nrow, 1.0);  // padding rows: 1 (never divides anything but 0)
+                for (int r = 0; r < dl.M.nrow; ++r)
+                    if (dl.global_of[r] >= 0) dg[r] = h.diag[dl.global_of[r]];
+                d.diag = upload(*this, dg.data(), dg.size());
+            } else {
             LocalOp la = extract_local(h.A, pl, pl, me);
             if (!upload_csr(*this, la.M, d.A, true) || !upload_plan(la.plan, d.planA)) return SPARSH_ENODEV;
             {  // slices whose rows reference no halo column can run while the exchange is in flight
@@ -529,6 +641,7 @@ int Engine::setup(const sparsh_params &p)
                 if (!bl.empty()) d.A.bnd_list = upload(*this, bl.data(), bl.size());
             }
             d.diag = upload(*this, h.diag.data() + pl.lo(me), (size_t)d.n);
+            }
             // P_l: my fine rows, columns in the coarse space (replicated coarse space: global columns)
             LocalOp lp = extract_local(h.P, pl, parts_[l + 1], me);
             // R_l: my share of the coarse rows; on the boundary to the replicated levels the share is
@@ -542,11 +655,26 @@ int Engine::setup(const sparsh_params &p)
             if (l > 0 && !lev_[l - 1].replicated) xh = std::max(xh, lev_[l - 1].planP.nhalo);  // x_l is also P_{l-1}'s input
             xcap = (size_t)d.n + xh;
             rcap = (size_t)d.n + d.planR.nhalo;
+            if (d.deep) {
+                xcap = (size_t)d.layer_end[d.K];                                   // own + padding + all ghost layers
+                rcap = std::max((size_t)d.npad, (size_t)d.n + d.planR.nhalo) + 64;  // residual over the own slices, then R's halo
+                // the prolongation reads the coarse iterate through a staging vector of its own: [own | P's halo]
+                d.xc_stage = static_cast<double *>(dalloc(((size_t)d.planP.nloc + d.planP.nhalo + 64) * 8));
+                if (!d.xc_stage) return SPARSH_ENODEV;
+                if (l == 0) {
+                    d.b_ext = static_cast<double *>(dalloc(xcap * 8));
+                    if (!d.b_ext || !check(hipMemsetAsync(d.b_ext, 0, xcap * 8, st_), "hipMemsetAsync")) return SPARSH_ENODEV;
+                }
+            }
         }
         d.x = static_cast<double *>(dalloc(xcap * 8));
         d.x2 = static_cast<double *>(dalloc(xcap * 8));
         d.r = static_cast<double *>(dalloc(rcap * 8));
-        if (l > 0) d.b = static_cast<double *>(dalloc((size_t)d.n * 8));
+        if (l > 0) {
+            const size_t bcap = d.deep ? xcap : (size_t)d.n;
+            d.b = static_cast<double *>(dalloc(bcap * 8));
+            if (d.b && !check(hipMemsetAsync(d.b, 0, bcap * 8, st_), "hipMemsetAsync")) return SPARSH_ENODEV;
+        }
         if (!d.diag || !d.x || !d.x2 || !d.r || (l > 0 && !d.b)) return SPARSH_ENODEV;
         if (l + 1 < nl) max_blk = std::max(max_blk, std::max(partial_count(d.P), partial_count(d.R)));
         max_blk = std::max(max_blk, partial_count(d.A));
@@ -585,7 +713,8 @@ int Engine::setup(const sparsh_params &p)
     if (!pinned_ && !check(hipHostMalloc(reinterpret_cast<void **>(&pinned_), 64 * sizeof(double), hipHostMallocDefault), "hipHostMalloc"))
         return SPARSH_ENODEV;
     work_.clear();
-    const size_t wcap = (size_t)lev_[0].n + lev_[0].planA.nhalo;  // Krylov vectors may be SpMV inputs: room for the halo
+    // Krylov vectors may be SpMV inputs: room for the halo (deep layout: padding + all ghost layers)
+    const size_t wcap = lev_[0].deep ? (size_t)lev_[0].layer_end[lev_[0].K] : (size_t)lev_[0].n + lev_[0].planA.nhalo;
     for (int k = 0; k < 8; ++k) {
         double *w = static_cast<double *>(dalloc(wcap * 8));
         if (!w) return SPARSH_ENODEV;
@@ -740,6 +869,7 @@ double Engine::read_hist(int it)
 bool Engine::halo(const DevPlan &p, double *vec)
 {
     if (!dist_) return true;
+    if (!p.empty()) ++n_exchanges_;
     return note_comm(comm_->exchange(p, vec, st_), "halo exchange");
 }
 
@@ -750,6 +880,7 @@ double Engine::bench_comm(int what, int level, int reps)
     if (what == 0 && L.replicated) return -1.0;
     if (what == 2 && (repl_level_ <= 0 || repl_level_ >= (int)lev_.size())) return -1.0;
     auto step = [&]() {
+        if (what == 0 && L.deep) return deep_exchange(L, 2, L.x);
         if (what == 0) return comm_->exchange(L.planA, L.x, st_);
         if (what == 1) return comm_->allreduce_sum(scal_ + S_SUM0, 2, st_);
         return comm_->allgather(lev_[repl_level_].r, gather_part_, st_);  // r of that level is scratch here
@@ -774,6 +905,10 @@ double Engine::bench_comm(int what, int level, int reps)
 int Engine::apply_A(DevLevel &L, CsrOp op, CsrArgs a)
 {
     double *xin = const_cast<double *>(a.x);
+    if (L.deep) {  // outside a smoothing leg: refresh the first ghost layer of the input, run the own slices
+        if (!deep_exchange(L, 0, xin)) return 0;
+        return launch_prefix(L, L.n, op, a);
+    }
     const CsrFamily fam = csr_family(L.A, cfg_);
     const bool sliced = fam == FAM_SDIA || fam == FAM_SDIA_TAB || fam == FAM_SELL;
     if (!(dist_ && overlap_ && !L.replicated && sliced && L.A.nint > 0 && L.A.nbnd > 0 && st2_)) {
@@ -869,6 +1004,11 @@ bool Engine::op_restrict(int l, const double *r, double *bc, bool fuse_zero)
 void Engine::op_prolong(int l, const double *xc, double *xf)
 {
     DevLevel &L = lev_[l];
+    if (L.deep && !lev_[l + 1].replicated) {
+        // the coarse iterate's own tail holds A_{l+1}'s ghost layers: P reads [own | its halo] from a staging vector
+        launch_copy(L.planP.nloc, xc, L.xc_stage, st_);
+        xc = L.xc_stage;
+    }
     halo(L.planP, const_cast<double *>(xc));
     if (L.P_is_aggregation) {
         launch_prolong_agg(L.n, L.P.col, xc, xf, st_);
@@ -894,6 +1034,39 @@ double Engine::op_dot(int n, const double *x, const double *y)
 // (the ping-pong partner L.x2 is scratch).  parallel::jacobi_smoother, src/AMG_smoothers.cpp:53-76.
 void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, double *dot_partial, int *dot_nblk, bool zero_done)
 {
+    if (L.deep) {
+        // Deep-halo leg: no exchange inside.  On entry b is valid on the layers <= K-1 and (unless x = 0) x on the
+        // layers <= K; sweep s leaves the layers <= K-s valid, so after `sweeps` <= K-1 sweeps the own rows and the
+        // first ghost layer hold exactly the global iterate.
+        const int K = L.K;
+        int s = 0;
+        const bool timed = prof.enabled && &L == &lev_[0] && prof.used + 2 <= prof.ev.size();
+        int in_run = 0;
+        if (x_zero && sweeps > 0) {
+            if (!zero_done) launch_jacobi_zero(L.layer_end[K - 1], b, L.diag, prm_.omega, L.x, st_);
+            s = 1;
+        }
+        if (timed) HIPCHK(hipEventRecord(prof.ev[prof.used], st_));
+        for (; s < sweeps; ++s) {
+            CsrArgs a;
+            a.x = L.x;
+            a.b = b;
+            a.d = L.diag;
+            a.y = L.x2;
+            a.omega = prm_.omega;
+            const int depth_left = std::max(K - (s + 1), 0);  // this is sweep s+1: it updates the layers <= K-(s+1)
+            launch_prefix(L, L.layer_end[depth_left], OP_JACOBI, a);
+            ++in_run;
+            std::swap(L.x, L.x2);
+        }
+        if (timed) {
+            HIPCHK(hipEventRecord(prof.ev[prof.used + 1], st_));
+            prof.run_launches.push_back(in_run);
+            prof.used += 2;
+        }
+        if (dot_partial) launch_dot(L.n, L.x, b, dot_partial, dot_nblk, st_);  // own rows only
+        return;
+    }
     int k = 0;
     bool dot_done = false;
     if (x_zero && sweeps > 0) {
@@ -957,6 +1130,26 @@ void Engine::vcycle(const double *b0, bool x0_zero, double *dot_partial, int *do
     bool zero_done = false;  // the previous level's restriction already wrote this level's zero-guess sweep
     for (int l = 0; l < last; ++l) {
         DevLevel &L = lev_[l];
+        if (L.deep) {
+            // deep-halo leg: one exchange of the right-hand side's ghost layers (and of the iterate's, unless it
+            // is zero) replaces the exchange in front of every sweep and of the residual
+            if (l == 0) {
+                launch_copy(L.n, b0, L.b_ext, st_);
+                L.b = L.b_ext;
+            }
+            deep_exchange(L, 1, L.b);
+            const bool xz = l > 0 || x0_zero;
+            if (!xz) deep_exchange(L, 2, L.x);
+            smooth(L, L.b, nu, xz, nullptr, nullptr, false);
+            CsrArgs a;  // residual on the own slices: x is valid on the first ghost layer
+            a.x = L.x;
+            a.b = L.b;
+            a.y = L.r;
+            launch_prefix(L, L.n, OP_RESID, a);
+            zero_done = false;
+            op_restrict(l, L.r, lev_[l + 1].b, false);
+            continue;
+        }
         smooth(L, L.b, nu, l > 0 || x0_zero, nullptr, nullptr, zero_done);  // coarse levels start from x = 0 (fill, :204)
         op_residual(l, L.b, L.x, L.r);                                      // store_residual
         zero_done = op_restrict(l, L.r, lev_[l + 1].b, nu > 0);             // transfer_residual (+ x_{l+1} = omega*b/d)
@@ -965,6 +1158,7 @@ void Engine::vcycle(const double *b0, bool x0_zero, double *dot_partial, int *do
     for (int l = last; l > 0; --l) {
         DevLevel &F = lev_[l - 1];
         op_prolong(l - 1, lev_[l].x, F.x);  // transfer_solution
+        if (F.deep) deep_exchange(F, 2, F.x);  // the leg's only exchange: K ghost layers of the prolongated iterate
         const bool want_dot = (l - 1 == 0) && dot_partial;
         smooth(F, F.b, nu, false, want_dot ? dot_partial : nullptr, dot_nblk);
     }

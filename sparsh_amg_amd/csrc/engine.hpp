@@ -18,6 +18,16 @@
 namespace sparsh {
 
 struct DevLevel {
+    // ---- deep-halo layout of a partitioned level (communication-avoiding smoothing, dist.hpp): the operator A
+    // and the vectors x, x2, b carry the own rows, padding to a slice boundary and K ghost layers
+    bool deep = false;
+    int K = 0;                       // ghost layers (sweeps + 1)
+    int npad = 0;                    // own rows rounded up to 64 = first ghost index
+    std::vector<int> layer_end;      // layer_end[d] = local indices in layers 0..d
+    DevDeepPlan dplan[3];            // exchange of ghost layers <= 1, <= K-1, <= K
+    std::vector<int> blk_first, wblk_first;  // first row of every CSR row block / wave block (prefix launches)
+    double *xc_stage = nullptr;      // prolongation input [own x_{l+1} | planP halo] (x_{l+1}'s own tail holds A's ghosts)
+    double *b_ext = nullptr;         // level 0: the right-hand side with room for its ghost layers
     int n = 0;       // rows this rank holds (all of them on a replicated level)
     int nglob = 0;   // rows of the level
     bool replicated = true;  // every rank holds and computes the whole level
@@ -92,6 +102,12 @@ public:
     // multi-GPU: install the transport before setup(); the engine owns it
     void set_comm(std::unique_ptr<Comm> c) { comm_ = std::move(c); }
     void set_overlap(bool on) { overlap_ = on; }
+    // deep halo (default on for partitioned runs): one exchange per smoothing leg instead of one per sweep; read at setup
+    void set_deep_halo(bool on) { deep_halo_ = on; }
+    bool deep_halo() const { return deep_halo_; }
+    long exchanges_issued() const { return n_exchanges_; }
+    // test hook: y[0, rows) = (A_l x_ext)[0, rows) on the local operator of a deep-halo level, no exchange
+    bool debug_prefix_spmv(int l, int rows, const double *x_ext, double *y);
     bool overlap() const { return overlap_; }
     Comm *comm() const { return comm_.get(); }
     bool distributed() const { return dist_; }
@@ -153,6 +169,11 @@ private:
     // zero_done: the zero-guess sweep x = omega*b/d has already been written to L.x (fused into the restriction)
     void smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, double *dot_partial, int *dot_nblk, bool zero_done = false);
     bool halo(const DevPlan &p, double *vec);  // pack + exchange (no-op on one GPU)
+    // deep-halo level: fill the ghost layers <= depth (which: 0 depth 1, 1 depth K-1, 2 depth K) of vec from their owners
+    bool deep_exchange(DevLevel &L, int which, double *vec);
+    // launch an A_l-type operator on the first `rows` local rows of a deep level (no exchange)
+    int launch_prefix(DevLevel &L, int rows, CsrOp op, const CsrArgs &a);
+    bool upload_deep_plan(const DeepPlan &h, DevDeepPlan &d);
     // A_l-type operator on level L: exchanges the halo of a.x, then launches; with overlap enabled the
     // exchange runs on a second stream while the slices that touch no halo column are processed.
     // Returns the number of reduction partials written.
@@ -177,6 +198,8 @@ private:
     int repl_level_ = 0;            // first replicated level (0: nothing is partitioned)
     bool dist_ = false;
     bool overlap_ = false;          // multi-GPU: overlap halo exchange with interior slices
+    bool deep_halo_ = true;         // multi-GPU: deep-halo smoothing on the partitioned levels
+    long n_exchanges_ = 0;          // transport calls issued (halo / staged exchanges; diagnostics)
     hipStream_t st2_ = nullptr;     // exchange stream of the overlap path
     hipEvent_t ev_ready_ = nullptr, ev_halo_ = nullptr;
     std::vector<F32Level> f32_;

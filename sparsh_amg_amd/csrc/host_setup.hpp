@@ -24,6 +24,9 @@ struct HostCsr {
     // global index of local row 0 (layout builders need the original entry order)
     std::vector<int> gcol_store;
     int grow0 = 0;
+    // deep-halo local operators: rows beyond the own block are ghost rows with arbitrary global indices
+    std::vector<int> grow_store;  // global row of every local row (empty: grow0 + r)
+    int grow(int r) const { return grow_store.empty() ? grow0 + r : grow_store[r]; }
 
     int nnz() const { return rowptr ? rowptr[nrow] : 0; }
     void adopt()

@@ -843,7 +843,9 @@ __global__ __launch_bounds__(kBlock) void sdia_tab_kernel(int nrow, int xlen, in
         const int sl = slist ? slist[idx] : idx;  // wave-uniform address: scalar load
         int row = sl * 64 + lane;
         const bool has_row = row < nrow;
-        if (!has_row) row = nrow - 1;
+        // lanes past the launched rows keep their own index while it is inside the vector: on a prefix launch of a
+        // deep-halo operator they are real rows, and the lane next door takes x[r+1] from their centre gather
+        if (!has_row) row = row < xlen ? row : xlen - 1;
         const unsigned long long *mrec = sd_tmask + (size_t)sl * 8;
         const int *cp = sd_tconf + sl;
         bool conform = false;
@@ -1381,6 +1383,13 @@ __global__ __launch_bounds__(kBlock) void pack_kernel(int n, const int *__restri
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) out[i] = vec[idx[i]];
 }
 
+// vec[pos[k]] = buf[k]: scatter a received staging buffer to the ghost positions (deep-halo exchange)
+__global__ __launch_bounds__(kBlock) void unpack_kernel(int n, const int *__restrict__ pos, const double *__restrict__ buf,
+                                                         double *__restrict__ vec)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) vec[pos[i]] = buf[i];
+}
+
 // 4-byte-per-lane streaming copy: calibrates rocprof's FETCH_SIZE for int32 index streams
 __global__ __launch_bounds__(kBlock) void copy_int_kernel(int n, const int *__restrict__ x, int *__restrict__ y)
 {
@@ -1796,6 +1805,12 @@ void launch_pack(int n, const int *idx, const double *vec, double *sendbuf, hipS
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(pack_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, st, n, idx, vec, sendbuf);
+}
+
+void launch_unpack(int n, const int *pos, const double *buf, double *vec, hipStream_t st)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(unpack_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, st, n, pos, buf, vec);
 }
 
 void launch_cg_update(int n, const double *scal, const double *p, const double *Ap, double *x, double *r, double *partial,

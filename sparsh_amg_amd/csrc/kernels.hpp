@@ -212,6 +212,8 @@ void launch_finalize(Fin code, const double *partial0, const double *partial1, i
                      int nblk1 = -1);  // nblk1: length of partial1 when it differs from nblk
 // sendbuf[k] = vec[idx[k]] : pack the entries the peers need (halo exchange)
 void launch_pack(int n, const int *idx, const double *vec, double *sendbuf, hipStream_t st);
+// vec[pos[k]] = buf[k] : scatter received ghost-layer entries to their local positions (deep-halo exchange)
+void launch_unpack(int n, const int *pos, const double *buf, double *vec, hipStream_t st);
 
 // Krylov vector updates with device-resident coefficients (no host round trip)
 // PCG/CG: x += alpha p ; r += (-alpha) Ap ; partial += r_i^2

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 QUIET = dict(print_setup=0, print_solve=0)
 
 
-def run_ranks(rp, ci, v, b, G, method, overlap=False, **kw):
+def run_ranks(rp, ci, v, b, G, method, overlap=False, deep=None, **kw):
     group = sa.comm_group_create(G)
     out = [None] * G
     errs = []
@@ -24,18 +24,23 @@ def run_ranks(rp, ci, v, b, G, method, overlap=False, **kw):
         try:
             A = sa.sp_matrix_mg(rp, ci, v)
             A.comm_init_group(group, r)
+            if deep is not None or overlap:
+                A.set_deep_halo(bool(deep) and not overlap)  # the overlapped schedule belongs to the per-sweep exchange path
             A.setup(sa.default_params(**QUIET, **kw))
             if overlap:
                 A.set_overlap(True)
             lo, hi, rep = A.local_range(0)
+            ex0 = A.exchanges_issued()
             x = np.zeros(hi - lo)
             if method in ("vcycle3", "comm"):
                 h, rc = A.vcycle(b[lo:hi].copy(), x, iterations=3)
             else:
                 h, rc = A.solve(method, b[lo:hi].copy(), x)
             out[r] = (lo, hi, rep, x, h, rc, [A.local_range(l) for l in range(A.nlevels)], A.level_format(0)[0])
+            exchanges = A.exchanges_issued() - ex0
             if method == "comm":  # the communication micro-benchmarks are collective calls too
                 out[r] = out[r] + ((A.bench_comm("halo", 0, 3), A.bench_comm("allreduce", 0, 3), A.bench_comm("allgather", 0, 3)),)
+            out[r] = out[r] + ({"exchanges": exchanges},)
             A.close()
         except Exception as e:  # noqa: BLE001
             errs.append((r, repr(e)))
@@ -238,3 +243,98 @@ def test_transport_failure_is_reported_not_swallowed():
     sa.comm_group_destroy(group)
     for codes, msg in res:
         assert codes == [sa.SPARSH_ECOMM, sa.SPARSH_ECOMM], (codes, msg)   # second call: sticky
+
+
+@pytest.mark.parametrize("G", [2, 3, 8])
+def test_deep_halo_same_rows_fewer_exchanges(G):
+    """Deep-halo smoothing (default): a rank carries K = sweeps + 1 ghost layers, exchanges them once per smoothing leg
+    and sweeps a shrinking row set.  Row by row it is the arithmetic of the per-sweep-exchange schedule and of the
+    one-rank cycle: a fixed number of V-cycles gives BITWISE the same solution; the transport is called ~4x less."""
+    rp, ci, v = problems.poisson3d(48)
+    n = len(rp) - 1
+    b = np.random.default_rng(9).standard_normal(n)
+    A1 = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET))
+    x1 = np.zeros(n)
+    A1.vcycle(b, x1, iterations=3)
+    deep = run_ranks(rp, ci, v, b, G, "vcycle3", deep=True, replicate_rows=4000)
+    flat = run_ranks(rp, ci, v, b, G, "vcycle3", deep=False, replicate_rows=4000)
+    xd = np.concatenate([r[3] for r in sorted(deep, key=lambda t: t[0])])
+    xf = np.concatenate([r[3] for r in sorted(flat, key=lambda t: t[0])])
+    assert np.array_equal(xd, x1) and np.array_equal(xf, x1)
+    assert sum(1 for (lo, hi, rep) in deep[0][6] if not rep) >= 3          # several partitioned levels
+    ed, ef = deep[0][-1]["exchanges"], flat[0][-1]["exchanges"]
+    assert ed * 3 < ef, (ed, ef)
+    # other sweep counts cut the legs differently (K = sweeps + 1 layers)
+    for nu in (1, 2, 4):
+        A1 = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET, sweeps=nu))
+        x1 = np.zeros(n)
+        A1.vcycle(b, x1, iterations=3)
+        res = run_ranks(rp, ci, v, b, G, "vcycle3", deep=True, replicate_rows=4000, sweeps=nu)
+        x = np.concatenate([r[3] for r in sorted(res, key=lambda t: t[0])])
+        assert np.array_equal(x, x1), nu
+
+
+def test_deep_halo_unstructured_and_beck():
+    """Ghost layers on a ragged operator (layers found by graph distance, owners anywhere) and with Beck's general P / R."""
+    for gen, kw in ((lambda: problems.fem_unstructured(30000, seed=5), dict(replicate_rows=3000)),
+                    (lambda: problems.poisson3d(36), dict(replicate_rows=3000, coarsening=1))):
+        rp, ci, v = gen()
+        n = len(rp) - 1
+        b = np.random.default_rng(1).standard_normal(n) * 1e-3
+        A1 = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET, **{k: w for k, w in kw.items() if k != "replicate_rows"}))
+        x1 = np.zeros(n)
+        A1.vcycle(b, x1, iterations=3)
+        h1p, _ = A1.solve("pcg", b, np.zeros(n))
+        for G in (2, 4):
+            res = run_ranks(rp, ci, v, b, G, "vcycle3", deep=True, **kw)
+            assert not res[0][2]
+            x = np.concatenate([r[3] for r in sorted(res, key=lambda t: t[0])])
+            assert np.array_equal(x, x1)
+            resp = run_ranks(rp, ci, v, b, G, "pcg", deep=True, **kw)
+            hp = resp[0][4]
+            assert len(hp) == len(h1p)
+            tol = np.where(h1p >= 1e-6 * h1p[0], 1e-8, 1e-4)
+            assert np.all(np.abs(hp - h1p) <= tol * h1p)
+
+
+def test_deep_halo_local_operator_every_family_every_prefix():
+    """The rank-local operator of a deep-halo level (own rows | padding | ghost layers) through every kernel family over
+    every row prefix a smoothing leg launches: bitwise equal.  Guards two things the ghost rows exposed: a prefix that
+    ends inside a slice (the table kernel takes x[r+1] from the neighbouring lane's gather, so lanes past the prefix must
+    keep their own row), and ghost rows whose neighbours in other layers sit at local offsets of the opposite sign
+    (+plane <-> -plane: such a slice matches the level's stencil as a set but not in order, and must leave the table path)."""
+    rp, ci, v = problems.poisson3d(48)
+    G = 2
+    group = sa.comm_group_create(G)
+    errs, seen = [], []
+
+    def work(r):
+        try:
+            A = sa.sp_matrix_mg(rp, ci, v)
+            A.comm_init_group(group, r)
+            A.setup(sa.default_params(**QUIET, replicate_rows=60000))
+            info = A.deep_info(0)
+            assert info["K"] == 8 and info["layer_end"][0] == info["npad"]
+            lo, hi, _ = A.local_range(0)
+            xe = np.random.default_rng(5 + r).standard_normal(info["cols"])
+            for rows in [hi - lo] + info["layer_end"][:-1]:
+                ys = {}
+                for kind in (0, 1, 2, 3):
+                    A.set_kernel_config(kind=kind)
+                    ys[A.level_kernel(0)] = A.deep_prefix_spmv(0, rows, xe)
+                seen.append(set(ys))
+                ref = ys["csr_block_kernel"]
+                for name, y in ys.items():
+                    assert np.array_equal(y, ref), (r, rows, name, int(np.flatnonzero(y != ref)[0]))
+            A.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in ts) and not errs, errs
+    sa.comm_group_destroy(group)
+    assert any("sdia_tab_kernel" in s for s in seen)
