@@ -244,8 +244,9 @@ int sparsh_profile(sparsh_handle h, int enable);
 int sparsh_profile_read(sparsh_handle h, double *out4);
 
 /* ---- multi-GPU (new design; the reference is single-GPU).  One process per GPU.  Every level
- * above params.replicate_rows is split into contiguous row blocks, one per rank; before each
- * SpMV-type kernel the neighbours' boundary entries of the input vector travel over RCCL (grouped
+ * above params.replicate_rows is split into contiguous row blocks, one per rank; a smoothing leg
+ * exchanges the ghost layers of its vectors once (deep halo, see sparsh_set_deep_halo), every other
+ * SpMV-type kernel the neighbours' boundary entries of its input vector, over RCCL (grouped
  * ncclSend/ncclRecv, xGMI); fused scalars are all-reduced; smaller levels and the coarsest solve
  * are computed by every rank.  All ranks run the same host setup on the whole matrix.
  * Bootstrap: rank 0 calls sparsh_comm_unique_id, the 128 bytes travel by any side channel
@@ -297,6 +298,16 @@ int sparsh_comm_group_fail_after(void *group, int ncalls);
 int sparsh_dist_local_op(sparsh_handle h, int level, int which, int rank, int nranks, int *sizes8);
 int sparsh_dist_local_op_get(sparsh_handle h, int *rowptr, int *col, double *val, int *halo_global, int *send_idx, int *send_segs3,
                              int *recv_segs3);
+
+/* Host-only planning query of the deep-halo layout (after sparsh_setup_host): the block of A_level that `rank` of `nranks`
+ * holds with K ghost layers, and its exchange plan of the given depth.  sizes8 = {local rows (own + padding + layers <= K-1),
+ * nnz, own rows, first ghost index (own rows rounded up to 64), local indices (all layers), send segments, receive segments,
+ * packed send entries}.  _get copies: local CSR (local column numbering), global index of every local index (-1: padding),
+ * layer_end[0..K], own indices to pack, (peer, offset, count) of the send segments, local position of every received entry,
+ * (peer, offset, count) of the receive segments. */
+int sparsh_dist_deep_op(sparsh_handle h, int level, int rank, int nranks, int K, int depth, int *sizes8);
+int sparsh_dist_deep_op_get(sparsh_handle h, int *rowptr, int *col, double *val, int *global_of, int *layer_end, int *send_idx,
+                            int *send_segs3, int *recv_pos, int *recv_segs3);
 
 #ifdef __cplusplus
 }

@@ -109,6 +109,8 @@ def _load():
         "sparsh_comm_group_create": (C.c_int, [C.c_int, P(C.c_void_p)]),
         "sparsh_comm_group_destroy": (None, [C.c_void_p]),
         "sparsh_set_deep_halo": (C.c_int, [H, C.c_int]),
+        "sparsh_dist_deep_op": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p]),
+        "sparsh_dist_deep_op_get": (C.c_int, [H, c_int_p, c_int_p, c_dbl_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]),
         "sparsh_deep_info": (C.c_int, [H, C.c_int, c_int_p]),
         "sparsh_deep_layer_end": (C.c_int, [H, C.c_int, C.c_int, c_int_p]),
         "sparsh_deep_prefix_spmv": (C.c_int, [H, C.c_int, C.c_int, c_dbl_p, c_dbl_p]),
@@ -408,6 +410,31 @@ class sp_matrix_mg:
         M = sp.csr_matrix((v[:nnz], ci[:nnz], rp), shape=(nrow, nloc + nhalo))
         plan = dict(nloc=nloc, nhalo=nhalo, row0=row0, halo_global=hg[:nhalo], send_idx=si[:nsend],
                     send=ss[: 3 * nss].reshape(-1, 3), recv=rs[: 3 * nrs].reshape(-1, 3))
+        return M, plan
+
+    def dist_deep_op(self, level, rank, nranks, K, depth):
+        """Host-only planning query of the deep-halo layout: (scipy local matrix, plan dict)."""
+        import scipy.sparse as sp
+
+        sz = (C.c_int * 8)()
+        _check(lib.sparsh_dist_deep_op(self._h, level, rank, nranks, K, depth, sz))
+        nrow, nnz, nloc, npad, nall, nss, nrs, nsend = list(sz)
+        rp = np.zeros(nrow + 1, dtype=np.int32)
+        ci = np.zeros(max(nnz, 1), dtype=np.int32)
+        v = np.zeros(max(nnz, 1))
+        gof = np.zeros(max(nall, 1), dtype=np.int32)
+        le = np.zeros(K + 1, dtype=np.int32)
+        si = np.zeros(max(nsend, 1), dtype=np.int32)
+        ss = np.zeros(max(3 * nss, 1), dtype=np.int32)
+        rs = np.zeros(max(3 * nrs, 1), dtype=np.int32)
+        nrecv_max = max(nall - npad, 1)
+        rpos = np.zeros(nrecv_max, dtype=np.int32)
+        _check(lib.sparsh_dist_deep_op_get(self._h, _ip(rp), _ip(ci), _dp(v), _ip(gof), _ip(le), _ip(si), _ip(ss), _ip(rpos), _ip(rs)))
+        M = sp.csr_matrix((v[:nnz], ci[:nnz], rp), shape=(nrow, nall))
+        recv = rs[: 3 * nrs].reshape(-1, 3)
+        nrecv = int(recv[:, 2].sum()) if len(recv) else 0
+        plan = dict(nloc=nloc, npad=npad, nall=nall, global_of=gof[:nall], layer_end=le, send_idx=si[:nsend],
+                    send=ss[: 3 * nss].reshape(-1, 3), recv=recv, recv_pos=rpos[:nrecv])
         return M, plan
 
     # -- solvers (host vectors) ------------------------------------------------------------

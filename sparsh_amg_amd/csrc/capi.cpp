@@ -18,6 +18,7 @@ using namespace sparsh;
 struct sparsh_handle_s {
     std::unique_ptr<Engine> eng;
     LocalOp cached_op;  // last sparsh_dist_local_op result
+    DeepLocal cached_deep;  // last sparsh_dist_deep_op result
 };
 
 namespace {
@@ -571,6 +572,55 @@ int sparsh_dist_local_op_get(sparsh_handle h, int *rowptr, int *col, double *val
         recv_segs3[3 * k] = o.plan.recv[k].peer;
         recv_segs3[3 * k + 1] = o.plan.recv[k].off;
         recv_segs3[3 * k + 2] = o.plan.recv[k].cnt;
+    }
+    return SPARSH_OK;
+}
+
+int sparsh_dist_deep_op(sparsh_handle h, int level, int rank, int nranks, int K, int depth, int *sizes8)
+{
+    REQUIRE_HOST(h);
+    REQUIRE_LEVEL(h, level);
+    if (nranks < 2 || rank < 0 || rank >= nranks || K < 1 || depth < 1 || depth > K) return fail(SPARSH_EINVAL, "bad arguments");
+    const HostHierarchy &H = h->eng->host();
+    std::vector<Partition> parts((size_t)level + 1);
+    for (int l = 0; l <= level; ++l)
+        parts[l] = (l == 0) ? make_partition(H.levels[0].A.nrow, nranks) : coarse_partition(H.levels[l - 1].R, parts[l - 1]);
+    h->cached_deep = extract_local_deep(H.levels[level].A, parts[level], rank, K, {depth});
+    const DeepLocal &d = h->cached_deep;
+    sizes8[0] = d.M.nrow;
+    sizes8[1] = d.M.nnz();
+    sizes8[2] = d.nloc;
+    sizes8[3] = d.npad;
+    sizes8[4] = (int)d.global_of.size();
+    sizes8[5] = (int)d.plans[0].send.size();
+    sizes8[6] = (int)d.plans[0].recv.size();
+    sizes8[7] = (int)d.plans[0].send_idx.size();
+    return SPARSH_OK;
+}
+
+int sparsh_dist_deep_op_get(sparsh_handle h, int *rowptr, int *col, double *val, int *global_of, int *layer_end, int *send_idx,
+                            int *send_segs3, int *recv_pos, int *recv_segs3)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    const DeepLocal &d = h->cached_deep;
+    if (!d.M.rowptr) return fail(SPARSH_ESTATE, "call sparsh_dist_deep_op first");
+    const DeepPlan &pl = d.plans[0];
+    std::memcpy(rowptr, d.M.rowptr, sizeof(int) * ((size_t)d.M.nrow + 1));
+    std::memcpy(col, d.M.col, sizeof(int) * (size_t)d.M.nnz());
+    std::memcpy(val, d.M.val, sizeof(double) * (size_t)d.M.nnz());
+    std::copy(d.global_of.begin(), d.global_of.end(), global_of);
+    std::copy(d.layer_end.begin(), d.layer_end.end(), layer_end);
+    std::copy(pl.send_idx.begin(), pl.send_idx.end(), send_idx);
+    std::copy(pl.recv_pos.begin(), pl.recv_pos.end(), recv_pos);
+    for (size_t k = 0; k < pl.send.size(); ++k) {
+        send_segs3[3 * k] = pl.send[k].peer;
+        send_segs3[3 * k + 1] = pl.send[k].off;
+        send_segs3[3 * k + 2] = pl.send[k].cnt;
+    }
+    for (size_t k = 0; k < pl.recv.size(); ++k) {
+        recv_segs3[3 * k] = pl.recv[k].peer;
+        recv_segs3[3 * k + 1] = pl.recv[k].off;
+        recv_segs3[3 * k + 2] = pl.recv[k].cnt;
     }
     return SPARSH_OK;
 }
