@@ -274,6 +274,8 @@ def main():
             return 8 * stored + meta + 24 * nrow
         if fmt == 2:
             return 12 * stored + 4 * nrow + 24 * nrow
+        if H.level_kernel(0) == "csr_rowlane_kernel":
+            return 12 * nnz_l + 28 * nrow  # CSR-stream with the diagonal picked out of the value stream: diag[] is not read
         return 12 * nnz_l + 36 * nrow  # CSR-stream: rowptr, col, val, d, b, x, x_new = the SURVEY 8d model itself
 
     def kernel_label(H):
@@ -349,7 +351,9 @@ def main():
     if world == 1 and mode == "single" and not args.no_families:
         families = {}
         runs = [("general_values_layout", dict(fold=False, cfg=None), "constant-slot folding off: sliced diagonals with 8 B per stored entry, no column indices"),
-                ("csr_stream_kind0", dict(fold=True, cfg=(0, 1, -1, -1)), "workgroup CSR-stream kernels forced on every level: rowptr + colindex + val streamed (12 B per entry)"),
+                ("csr_stream_kind0", dict(fold=True, cfg=(0, 3, -1, -1)), "workgroup CSR-stream kernels forced on every level: rowptr + colindex + val streamed (12 B per entry); "
+                                                                        "levels that stream from HBM run csr_rowlane_kernel (gathers in row-lane order), cache-resident ones csr_block_kernel"),
+                ("csr_stream_kind0_block_kernel", dict(fold=True, cfg=(0, 1, -1, -1)), "the same with the round-1 csr_block_kernel (gathers in CSR order) on every level"),
                 ("sliced_ell_kind2", dict(fold=True, cfg=(2, 0, -1, -1)), "sliced-ELL mirror forced where it exists (12 B per padded entry)")]
         for key, kw, note in runs:
             log(f"kernel family run: {key}")

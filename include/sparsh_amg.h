@@ -107,8 +107,9 @@ int sparsh_set_stopping(sparsh_handle h, double tol, int max_iter, int check_eve
 /* Per-handle choice of the SpMV-type kernel family (A/B measurements; all families produce
  * bitwise identical results; nothing here is process-wide state).  kind: 0 workgroup CSR-stream, 1 wave CSR-stream, 2 sliced-ELL mirror,
  * 3 sliced-diagonal mirror (default); 2 and 3 fall back (3 -> 2 -> 0) where the operator does not
- * qualify for the mirror; vec: paired 16-B/8-B loads in
- * the stream phase; nt: non-temporal loads for the matrix stream; remap: 0 none, 1 each XCD owns a
+ * qualify for the mirror; vec (CSR-stream kernels): 0 one entry per load, 1 paired 16-B/8-B loads in the stream phase,
+ * 2 col/val staged in LDS with the x gathers issued in row-lane order (csr_rowlane_kernel), 3 (default) = 2 for operators
+ * that stream from HBM, 1 for cache-resident ones; nt: non-temporal loads for the matrix stream; remap: 0 none, 1 each XCD owns a
  * contiguous eighth of the row blocks, G > 1 groups of G row blocks dealt round-robin to the XCDs.
  * nt < 0 or remap < 0 selects the built-in per-operator policy (default). */
 int sparsh_set_kernel_config(sparsh_handle h, int kind, int vec, int nt, int remap);

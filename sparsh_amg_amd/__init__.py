@@ -259,7 +259,7 @@ class sp_matrix_mg:
         _check(lib.sparsh_level_tile_rows(self._h, level, C.byref(r)))
         return r.value
 
-    def set_kernel_config(self, kind=3, vec=1, nt=-1, remap=-1):
+    def set_kernel_config(self, kind=3, vec=3, nt=-1, remap=-1):
         """Select the SpMV-type kernel family of this handle; see sparsh_set_kernel_config."""
         _check(lib.sparsh_set_kernel_config(self._h, int(kind), int(vec), int(nt), int(remap)))
         return self

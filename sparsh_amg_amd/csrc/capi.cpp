@@ -197,7 +197,7 @@ int sparsh_set_kernel_config(sparsh_handle h, int kind, int vec, int nt, int rem
     if (kind < 0 || kind > 3) return fail(SPARSH_EINVAL, "kind must be 0 (workgroup CSR-stream), 1 (wave CSR-stream), 2 (sliced ELL) or 3 (sliced diagonals)");
     KernelConfig &c = h->eng->kernel_cfg();
     c.kind = kind;
-    c.vec = vec != 0 ? 1 : 0;
+    c.vec = vec < 0 ? 0 : (vec > 3 ? 3 : vec);
     c.nt = nt > 0;
     c.remap = remap < 0 ? 0 : remap;
     c.auto_policy = (nt < 0 || remap < 0);

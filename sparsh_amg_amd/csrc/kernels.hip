@@ -306,6 +306,126 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(const int *__restrict
     }
 }
 
+// csr_rowlane_kernel (kind 0, vec = 2): the CSR-stream kernel with the x gathers issued in ROW-LANE order.
+// Counters (profiles/r02_pmc/diag_csr_block_vs_sell_counters.txt) show csr_block_kernel address-unit bound: TA busy 93 % of
+// the launch, 99 M L1 accesses per sweep against 54 M for the sliced-ELL kernel -- its gathers run in CSR order, where the 64
+// lanes of one instruction cover ~9 rows x 7 columns = a dozen cache lines.  Here phase 1 only copies the block's col/val
+// run into LDS (coalesced, no gathers); in phase 2 lane = row walks its entries in stored order reading (col, val) from LDS
+// and gathering x[col]: the k-th entries of 64 consecutive rows of a banded / mesh-ordered operator are neighbours in x, so
+// a gather touches 4-6 lines instead of 12.  Same rounded products, same order of additions.  The diagonal is picked out of
+// the stream (col == row), so diag[] is not read.
+template <int OP, bool NT, int TAG>
+__global__ __launch_bounds__(kBlock) void csr_rowlane_kernel(const int *__restrict__ rowblk, int nblk, int remap,
+                                                              const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                              const double *__restrict__ val, CsrArgs a)
+{
+    __shared__ double sval[kStreamNnz];
+    __shared__ int scol[kStreamNnz];
+    __shared__ double red[kBlock / 64];
+    const int bid = remap ? xcd_remap(blockIdx.x, nblk, remap) : blockIdx.x;
+    if (bid >= nblk) return;  // whole workgroup leaves together
+    const int tid = threadIdx.x;
+    const int4 br = reinterpret_cast<const int4 *>(rowblk)[bid];
+    const int r0 = br.x, r1 = br.y;
+    const int nrows = r1 - r0;
+    const int j0 = br.z, j1 = br.w;
+    const double *__restrict__ x = a.x;
+    const bool has_row = tid < nrows;
+    const int row = r0 + tid;
+    int s = 0, e = 0;
+    RowOperands o;
+    if (has_row) {
+        s = rowptr[row] - j0;
+        e = rowptr[row + 1] - j0;
+        o = load_row_operands<OP, false>(a, row);
+    }
+    double sum = 0.0;
+    bool store = has_row;
+    if (nrows == 1 && j1 - j0 > kStreamNnz) {  // one long row: strided partial sums, tree-combined (as csr_block_kernel)
+        double part = 0.0, dv = 0.0;
+        for (int j = j0 + tid; j < j1; j += kBlock) {
+            const int c = ld_stream<NT>(col + j);
+            const double v = ld_stream<NT>(val + j);
+            part += v * x[c];
+            if (c == row) dv = v;
+        }
+        part = block_sum(part, red);
+        __syncthreads();
+        dv = block_sum(dv, red);  // exactly one thread holds the diagonal entry (others 0)
+        __syncthreads();
+        red[0] = dv;
+        __syncthreads();
+        o.di = red[0];
+        sum = part;
+        store = (tid == 0);
+    } else {
+        // phase 1: the block's col/val run -> LDS, paired 8-B / 16-B loads at even indices (col/val carry kCsrPad zeroed tail entries)
+        if (j1 > j0) {
+            const int jb = j0 & ~1;
+            const int jlast = (j1 - 1) & ~1;
+            constexpr int U = 2;
+            for (int j = jb + 2 * tid; j < j1; j += 2 * U * kBlock) {
+                i2v c[U];
+                d2v v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    int jj = j + 2 * u * kBlock;
+                    jj = jj < jlast ? jj : jlast;
+                    if constexpr (NT) {
+                        c[u] = __builtin_nontemporal_load(reinterpret_cast<const i2v *>(col + jj));
+                        v[u] = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(val + jj));
+                    } else {
+                        c[u] = *reinterpret_cast<const i2v *>(col + jj);
+                        v[u] = *reinterpret_cast<const d2v *>(val + jj);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int jj = j + 2 * u * kBlock;
+                    if (jj >= j0 && jj < j1) {
+                        scol[jj - j0] = c[u].x;
+                        sval[jj - j0] = v[u].x;
+                    }
+                    if (jj + 1 >= j0 && jj + 1 < j1) {
+                        scol[jj + 1 - j0] = c[u].y;
+                        sval[jj + 1 - j0] = v[u].y;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // phase 2: lane = row; entries in stored order, eight (col, val) pairs and their gathers in flight at a time
+        double dv = 0.0;
+        for (int k = s; k < e; k += 8) {
+            int c[8];
+            double v[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kk = k + u < e ? k + u : e - 1;
+                c[u] = scol[kk];
+                v[u] = sval[kk];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = x[c[u]];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double t = v[u] * xv[u];
+                const bool on = k + u < e;
+                sum = on ? sum + t : sum;
+                dv = (on && c[u] == row) ? v[u] : dv;
+            }
+        }
+        o.di = dv;
+    }
+    double acc = 0.0;
+    if (store) acc = row_epilogue<OP>(a, row, sum, o);
+    if constexpr (op_reduces(OP)) {
+        __syncthreads();
+        const double t = block_sum(acc, red);
+        if (tid == 0) a.partial[bid] = t;
+    }
+}
+
 template <int OP, bool NT, int VEC, int TAG>
 __global__ __launch_bounds__(kBlock) void csr_wave_kernel(const int *__restrict__ waveblk, int nwblk, int ngroups, int remap,
                                                            const int *__restrict__ rowptr, const int *__restrict__ col,
@@ -1222,12 +1342,19 @@ int launch_csr_tagged(const DevCsr &A, const CsrArgs &a, bool nt, int remap, hip
     }
     if (A.nblk <= 0) return 0;
     const int grid = remap_grid(A.nblk, remap);
+    if (fam == FAM_CSR_ROWLANE) {  // gathers in row-lane order (col/val staged in LDS)
+        if (nt)
+            hipLaunchKernelGGL((csr_rowlane_kernel<OP, true, TAG>), dim3(grid), dim3(kBlock), 0, st, A.rowblk, A.nblk, remap, A.rowptr, A.col, A.val, a);
+        else
+            hipLaunchKernelGGL((csr_rowlane_kernel<OP, false, TAG>), dim3(grid), dim3(kBlock), 0, st, A.rowblk, A.nblk, remap, A.rowptr, A.col, A.val, a);
+        return A.nblk;
+    }
 #define SPARSH_LAUNCH_BLOCK(NT_, VEC_) \
     hipLaunchKernelGGL((csr_block_kernel<OP, NT_, VEC_, TAG>), dim3(grid), dim3(kBlock), 0, st, A.rowblk, A.nblk, remap, A.rowptr, A.col, A.val, a)
     if (nt && c.vec) SPARSH_LAUNCH_BLOCK(true, 1);
     else if (nt) SPARSH_LAUNCH_BLOCK(true, 0);
     else if (c.vec) SPARSH_LAUNCH_BLOCK(false, 1);
-    else SPARSH_LAUNCH_BLOCK(false, 0);
+    else SPARSH_LAUNCH_BLOCK(false, 0);  // (vec = 3 below the HBM threshold runs the paired-load kernel)
 #undef SPARSH_LAUNCH_BLOCK
     return A.nblk;
 }
@@ -1243,6 +1370,9 @@ CsrFamily csr_family(const DevCsr &A, const KernelConfig &c)
     if (c.kind == 3 && A.has_sdia() && !small_prefers_ell) return FAM_SDIA;
     if (c.kind >= 2 && A.sell_val) return FAM_SELL;
     if (c.kind == 1 && A.waveblk) return FAM_CSR_WAVE;
+    // workgroup CSR-stream kernels: gathers in row-lane order when asked for, or (vec = 3) when the operator streams from HBM
+    const size_t csr_bytes = (size_t)A.nnz * 12 + (size_t)A.nrow * 36;
+    if (c.vec == 2 || (c.vec == 3 && csr_bytes > (240u << 20))) return FAM_CSR_ROWLANE;
     return FAM_CSR_BLOCK;
 }
 
@@ -1270,6 +1400,7 @@ const char *csr_family_name(CsrFamily f)
     case FAM_SDIA: return "sdia_kernel";
     case FAM_SELL: return "sell_kernel";
     case FAM_CSR_WAVE: return "csr_wave_kernel";
+    case FAM_CSR_ROWLANE: return "csr_rowlane_kernel";
     default: return "csr_block_kernel";
     }
 }

@@ -78,7 +78,9 @@ struct DevCsr {
 struct KernelConfig {
     int kind = 3;       // 0 workgroup CSR-stream, 1 wave CSR-stream, 2 sliced ELL, 3 sliced diagonals; 2 and 3 fall
                         // back (3 -> 2 -> 0) where the operator does not qualify for the mirror
-    int vec = 1;        // phase 1 of the CSR-stream kernels: 0 one entry per load, 1 two entries per lane (16-B val / 8-B col loads)
+    int vec = 3;        // CSR-stream kernels: 0 one entry per load, 1 two entries per lane (16-B val / 8-B col loads), 2 (workgroup kernel)
+                        // col/val staged in LDS and the x gathers issued in row-lane order (csr_rowlane_kernel), 3 = 2 for operators
+                        // that stream from HBM (> 240 MB of CSR bytes), 1 below (a cache-resident ragged operator is faster on 1)
     bool auto_policy = true;  // choose nt / remap per operator from its size (overrides the two below)
     bool nt = true;     // non-temporal loads for the matrix stream
     int remap = 1;      // 0 none, 1 XCD x owns the x-th contiguous eighth, G>1 groups of G row blocks dealt round-robin to XCDs
@@ -89,7 +91,7 @@ struct KernelConfig {
 
 // which kernel a launch of launch_csr on operator A runs under cfg (one decision, used by the
 // launcher and by every report of it)
-enum CsrFamily : int { FAM_CSR_BLOCK = 0, FAM_CSR_WAVE = 1, FAM_SELL = 2, FAM_SDIA = 3, FAM_SDIA_TAB = 4 };
+enum CsrFamily : int { FAM_CSR_BLOCK = 0, FAM_CSR_WAVE = 1, FAM_SELL = 2, FAM_SDIA = 3, FAM_SDIA_TAB = 4, FAM_CSR_ROWLANE = 5 };
 
 constexpr int kBlock = 256;       // threads per workgroup (4 waves)
 constexpr int kStreamNnz = 2048;  // products staged in LDS per workgroup (16 KiB)

@@ -68,7 +68,7 @@ def test_kernels_bitwise(case):
     assert np.linalg.norm(xg - xo) <= 1e-10 * np.linalg.norm(xo)
 
 
-KERNEL_CONFIGS = [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (3, 0)]
+KERNEL_CONFIGS = [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (2, 0), (3, 0)]  # (0, 2): CSR-stream with row-lane gathers
 
 
 @pytest.mark.parametrize("kind,vec", KERNEL_CONFIGS)

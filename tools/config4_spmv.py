@@ -31,7 +31,7 @@ def main():
     A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, print_solve=0))
     out["levels"] = [A.level_info(l)["nrow"] for l in range(A.nlevels)]
     out["coarsest"] = A.coarse_info()
-    for kind, vec in ((0, 1), (0, 0), (1, 1), (2, 0)):
+    for kind, vec in ((0, 1), (0, 2), (0, 0), (1, 1), (2, 0)):
         A.set_kernel_config(kind=kind, vec=vec)
         name = A.level_kernel(0)
         key = f"kind{kind}_vec{vec}:{name}"
