@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kBlock) void csr_rowlane_kernel(const int *__restri
                 v[u] = sval[kk];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) xv[u] = x[c[u]];
+            for (int u = 0; u < 8; ++u) xv[u] = (k + u < e) ? x[c[u]] : 0.0;  // lanes past their row's end issue no access (ragged rows)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const double t = v[u] * xv[u];
