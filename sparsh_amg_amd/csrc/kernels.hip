@@ -347,15 +347,12 @@ __global__ __launch_bounds__(kBlock) void csr_rowlane_kernel(const int *__restri
             const int c = ld_stream<NT>(col + j);
             const double v = ld_stream<NT>(val + j);
             part += v * x[c];
-            if (c == row) dv = v;
+            if (c == r0) dv = v;  // r0, not row: every thread of the workgroup works on the one long row
         }
         part = block_sum(part, red);
         __syncthreads();
-        dv = block_sum(dv, red);  // exactly one thread holds the diagonal entry (others 0)
-        __syncthreads();
-        red[0] = dv;
-        __syncthreads();
-        o.di = red[0];
+        dv = block_sum(dv, red);  // exactly one thread holds the diagonal entry (others 0): an exact sum, valid in thread 0
+        o.di = dv;                // thread 0 is the only one that runs the epilogue
         sum = part;
         store = (tid == 0);
     } else {

@@ -265,6 +265,7 @@ def test_edge_cases():
     rng = np.random.default_rng(5)
     M = sp.random(n, n, density=0.001, random_state=6, format="lil")
     M[17, :] = rng.standard_normal(n)  # 6000 entries > LDS product buffer
+    M[512, :] = rng.standard_normal(n)  # a second one at a multiple of the workgroup size (diagonal pick-up by r0, not r0 + tid)
     M[100, :] = 0
     M[101, :] = 0
     M = (M.tocsr() + sp.diags(np.full(n, 50.0))).tocsr()
@@ -272,14 +273,23 @@ def test_edge_cases():
     assert M.indptr[101] - M.indptr[100] == 1
     A2 = sa.sp_matrix_mg(M.indptr, M.indices, M.data).setup(sa.default_params(**QUIET, limit_upper=10000))
     x = rng.standard_normal(n)
-    y = A2.op_spmv(0, x)
-    yo = oracle.spmv(oracle.Csr(M.indptr, M.indices, M.data), x)
-    mask = np.ones(n, bool)
-    mask[17] = False
-    assert np.array_equal(y[mask], yo[mask])
-    assert abs(y[17] - yo[17]) <= 1e-12 * (np.abs(M[17].toarray()).ravel() @ np.abs(x))
     b = rng.standard_normal(n)
-    assert np.allclose(A2.op_jacobi(0, b, x, 3), oracle.jacobi(oracle.Csr(M.indptr, M.indices, M.data), b, x, 2), rtol=1e-12, atol=1e-12)
+    Mo = oracle.Csr(M.indptr, M.indices, M.data)
+    yo = oracle.spmv(Mo, x)
+    jo = oracle.jacobi(Mo, b, x, 2)
+    mask = np.ones(n, bool)
+    mask[[17, 512]] = False
+    seen = set()
+    # default family, then every CSR-stream variant by name: the long row takes the strided partial-sum branch of each
+    for kind, vec in ((3, 3), (0, 0), (0, 1), (0, 2), (1, 0)):
+        A2.set_kernel_config(kind=kind, vec=vec)
+        seen.add(A2.level_kernel(0))
+        y = A2.op_spmv(0, x)
+        assert np.array_equal(y[mask], yo[mask]), (kind, vec)
+        for r in (17, 512):
+            assert abs(y[r] - yo[r]) <= 1e-12 * (np.abs(M[r].toarray()).ravel() @ np.abs(x)), (kind, vec, r)
+        assert np.allclose(A2.op_jacobi(0, b, x, 3), jo, rtol=1e-12, atol=1e-12), (kind, vec)
+    assert any("rowlane" in k for k in seen), seen
 
 
 def test_max_iter_cap_reports_noconv():
