@@ -126,10 +126,12 @@ def main():
     kcfg = os.environ.get("SPARSH_BENCH_KCFG")  # A/B runs: "kind,vec,nt,remap" instead of the per-operator policy
     no_fold = os.environ.get("SPARSH_BENCH_NO_FOLD", "0") == "1"  # profile the general layout (what a variable-coefficient operator gets)
 
-    def new_handle(fold=True, cfg=None):
+    def new_handle(fold=True, cfg=None, idx16=None):
         H = sa.sp_matrix_mg(rp, ci, v)
         if not fold:
             H.set_const_slots(False)
+        if idx16 is not None:
+            H.set_index_compression(idx16)
         if cfg:
             H.set_kernel_config(*cfg)
         return H
@@ -276,6 +278,9 @@ def main():
             return 12 * stored + 4 * nrow + 24 * nrow
         if H.level_kernel(0) == "csr_rowlane_kernel":
             return 12 * nnz_l + 28 * nrow  # CSR-stream with the diagonal picked out of the value stream: diag[] is not read
+        if H.level_kernel(0) == "csr_rowlane16_kernel":
+            b16, nb = H.level_index16(0)  # 16-bit delta-coded column indices (+ 4 B of base per row block); blocks that keep col[] priced at 12 B
+            return int(round((10 * b16 + 12 * (nb - b16)) / max(nb, 1) * nnz_l)) + 4 * nb + 28 * nrow
         return 12 * nnz_l + 36 * nrow  # CSR-stream: rowptr, col, val, d, b, x, x_new = the SURVEY 8d model itself
 
     def kernel_label(H):
@@ -353,6 +358,8 @@ def main():
         runs = [("general_values_layout", dict(fold=False, cfg=None), "constant-slot folding off: sliced diagonals with 8 B per stored entry, no column indices"),
                 ("csr_stream_kind0", dict(fold=True, cfg=(0, 3, -1, -1)), "workgroup CSR-stream kernels forced on every level: rowptr + colindex + val streamed (12 B per entry); "
                                                                         "levels that stream from HBM run csr_rowlane_kernel (gathers in row-lane order), cache-resident ones csr_block_kernel"),
+                ("csr_stream_kind0_idx16", dict(fold=True, cfg=(0, 3, -1, -1), idx16=2), "CSR-stream with compressed column indices (SURVEY 8f-4): 16-bit deltas per row block, 10 B per entry; "
+                                                                                       "levels that stream from HBM run csr_rowlane16_kernel"),
                 ("csr_stream_kind0_block_kernel", dict(fold=True, cfg=(0, 1, -1, -1)), "the same with the round-1 csr_block_kernel (gathers in CSR order) on every level"),
                 ("sliced_ell_kind2", dict(fold=True, cfg=(2, 0, -1, -1)), "sliced-ELL mirror forced where it exists (12 B per padded entry)")]
         for key, kw, note in runs:

@@ -109,7 +109,8 @@ int sparsh_set_stopping(sparsh_handle h, double tol, int max_iter, int check_eve
  * 3 sliced-diagonal mirror (default); 2 and 3 fall back (3 -> 2 -> 0) where the operator does not
  * qualify for the mirror; vec (CSR-stream kernels): 0 one entry per load, 1 paired 16-B/8-B loads in the stream phase,
  * 2 col/val staged in LDS with the x gathers issued in row-lane order (csr_rowlane_kernel), 3 (default) = 2 for operators
- * that stream from HBM, 1 for cache-resident ones; nt: non-temporal loads for the matrix stream; remap: 0 none, 1 each XCD owns a
+ * that stream from HBM, 1 for cache-resident ones, 4 = 2 with 16-bit delta-coded column indices (csr_rowlane16_kernel) where the
+ * operator carries them (sparsh_set_index_compression); nt: non-temporal loads for the matrix stream; remap: 0 none, 1 each XCD owns a
  * contiguous eighth of the row blocks, G > 1 groups of G row blocks dealt round-robin to the XCDs.
  * nt < 0 or remap < 0 selects the built-in per-operator policy (default). */
 int sparsh_set_kernel_config(sparsh_handle h, int kind, int vec, int nt, int remap);
@@ -132,6 +133,16 @@ int sparsh_level_format(sparsh_handle h, int level, int *kind, long *stored_entr
  * handle (A/B measurements; default on). */
 int sparsh_level_layout(sparsh_handle h, int level, long *slots, long *value_blocks, long *meta_bytes);
 int sparsh_set_const_slots(sparsh_handle h, int enable);
+/* Compressed column indices for the CSR-stream family: per row block of the workgroup kernel the indices
+ * are also kept as 16-bit deltas (first entry of a row relative to the block's smallest first column, every further entry
+ * relative to the previous column of its row), 10 instead of 12 bytes per stored entry; blocks a delta does not fit (a gap
+ * of 65536 or more, an unsorted row, a single row longer than the LDS buffer) keep the 32-bit indices.  Same products, same
+ * order of additions: results are bitwise those of the other families.  mode, read by sparsh_setup: 0 never build the form,
+ * 1 (default) for operators the default policy streams from HBM through the CSR-stream kernel (> 240 MB, no sliced mirror),
+ * 2 for every operator (A/B measurements with sparsh_set_kernel_config(h, 0, 4, ...)).
+ * sparsh_level_index16: how many row blocks of a level's operator use the 16-bit form, out of how many. */
+int sparsh_set_index_compression(sparsh_handle h, int mode);
+int sparsh_level_index16(sparsh_handle h, int level, long *blocks16, long *blocks);
 /* Table levels of grid stencils (offsets -1, 0, +1, +-line[, +-plane]) run, on whole-level launches, a
  * variant that stages x[r0 - line, r0 + T + line) of every workgroup's T rows in LDS, so the centre, +-1 and
  * +-line neighbours come out of LDS and only the +-plane neighbours are gathered from L2 (bitwise the same

@@ -87,6 +87,8 @@ def _load():
         "sparsh_level_layout": (C.c_int, [H, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
         "sparsh_set_const_slots": (C.c_int, [H, C.c_int]),
         "sparsh_set_tile": (C.c_int, [H, C.c_int]),
+        "sparsh_set_index_compression": (C.c_int, [H, C.c_int]),
+        "sparsh_level_index16": (C.c_int, [H, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
         "sparsh_level_tile_rows": (C.c_int, [H, C.c_int, c_int_p]),
         "sparsh_bench_comm": (C.c_int, [H, C.c_int, C.c_int, C.c_int, c_dbl_p]),
         "sparsh_level_kernel": (C.c_char_p, [H, C.c_int]),
@@ -248,6 +250,17 @@ class sp_matrix_mg:
         """Layout option read by setup(): fold constant diagonals of a slice into one scalar."""
         _check(lib.sparsh_set_const_slots(self._h, int(bool(enable))))
         return self
+
+    def set_index_compression(self, mode=1):
+        """16-bit delta-coded column indices for the CSR-stream family (call before setup); see sparsh_set_index_compression."""
+        _check(lib.sparsh_set_index_compression(self._h, int(mode)))
+        return self
+
+    def level_index16(self, level):
+        """(row blocks of the level's operator in 16-bit index form, row blocks)."""
+        a, b = C.c_long(), C.c_long()
+        _check(lib.sparsh_level_index16(self._h, level, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def set_tile(self, enable=True):
         """LDS-tiled variant of the table kernel on whole-level launches of grid stencils (default on)."""

@@ -197,7 +197,7 @@ int sparsh_set_kernel_config(sparsh_handle h, int kind, int vec, int nt, int rem
     if (kind < 0 || kind > 3) return fail(SPARSH_EINVAL, "kind must be 0 (workgroup CSR-stream), 1 (wave CSR-stream), 2 (sliced ELL) or 3 (sliced diagonals)");
     KernelConfig &c = h->eng->kernel_cfg();
     c.kind = kind;
-    c.vec = vec < 0 ? 0 : (vec > 3 ? 3 : vec);
+    c.vec = vec < 0 ? 0 : (vec > 4 ? 3 : vec);
     c.nt = nt > 0;
     c.remap = remap < 0 ? 0 : remap;
     c.auto_policy = (nt < 0 || remap < 0);
@@ -297,6 +297,24 @@ int sparsh_set_const_slots(sparsh_handle h, int enable)
 {
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
     h->eng->kernel_cfg().const_slots = enable != 0;
+    return SPARSH_OK;
+}
+
+int sparsh_set_index_compression(sparsh_handle h, int mode)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    if (mode < 0 || mode > 2) return fail(SPARSH_EINVAL, "mode must be 0 (off), 1 (operators that stream from HBM through the CSR-stream kernel) or 2 (every operator)");
+    h->eng->kernel_cfg().idx16 = mode;
+    return SPARSH_OK;
+}
+
+int sparsh_level_index16(sparsh_handle h, int level, long *blocks16, long *blocks)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    const DevCsr &A = h->eng->level(level).A;
+    if (blocks16) *blocks16 = A.col16 ? A.nblk16 : 0;
+    if (blocks) *blocks = A.nblk;
     return SPARSH_OK;
 }
 

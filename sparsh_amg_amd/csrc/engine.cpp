@@ -386,8 +386,10 @@ bool upload_csr(Engine &E, const HostCsr &A, DevCsr &D, bool with_sell, const st
     D.col = upload_padded(E, A.col, (size_t)D.nnz);
     D.val = upload_padded(E, A.val, (size_t)D.nnz);
     std::vector<int> rb((size_t)A.nrow + 2);
+    std::vector<int> recs;  // the row-block records as uploaded
     if (!cuts) {
         const std::vector<int> rec = rowblock_records(A.nrow, A.rowptr, &D.nblk);
+        recs = rec;
         D.rowblk = upload(E, rec.data(), rec.size());
         D.nwblk = build_waveblocks(A.nrow, A.rowptr, rb.data());
         D.waveblk = upload(E, rb.data(), (size_t)D.nwblk + 1);
@@ -417,10 +419,22 @@ bool upload_csr(Engine &E, const HostCsr &A, DevCsr &D, bool with_sell, const st
         }
         D.nblk = (int)(rec.size() / 4);
         if (rec.empty()) rec.assign(4, 0);
+        recs = rec;
         D.rowblk = upload(E, rec.data(), rec.size());
         D.nwblk = (int)wb.size() - 1;
         D.waveblk = upload(E, wb.data(), wb.size());
     }
+    // 16-bit delta form of the column indices (csr_rowlane16_kernel): for every operator when asked for, by default for
+    // those the default policy streams from HBM through the CSR-stream kernel (decided below, once the mirrors exist)
+    const auto build16 = [&]() -> bool {
+        std::vector<unsigned short> c16((size_t)D.nnz + kCsrPad, 0);
+        std::vector<int> cb((size_t)std::max(D.nblk, 1), -1);
+        D.nblk16 = build_col16(A.rowptr, A.col, recs.data(), D.nblk, c16.data(), cb.data());
+        if (D.nblk16 == 0) return true;  // nothing fits: the operator keeps its 32-bit indices only
+        D.col16 = upload(E, c16.data(), c16.size());
+        D.cbase = upload(E, cb.data(), cb.size());
+        return D.col16 && D.cbase;
+    };
     if (with_sell && !upload_sell(E, A, D)) {
         if (E.error.empty()) E.error = "building the sliced-ELL mirror failed";
         return false;
@@ -428,6 +442,15 @@ bool upload_csr(Engine &E, const HostCsr &A, DevCsr &D, bool with_sell, const st
     if (with_sell && !upload_sdia(E, A, D)) {
         if (E.error.empty()) E.error = "building the sliced-diagonal mirror failed";
         return false;
+    }
+    if (D.nblk > 0 && D.rowblk) {
+        const int mode = E.kernel_cfg().idx16;
+        KernelConfig dflt;
+        const bool streams = csr_family(D, dflt) == FAM_CSR_ROWLANE;  // default policy: CSR-stream kernel, operator > 240 MB (col16 not built yet)
+        if ((mode == 2 || (mode == 1 && streams)) && !build16()) {
+            if (E.error.empty()) E.error = "building the 16-bit column index form failed";
+            return false;
+        }
     }
     if (!(D.rowptr && D.col && D.val && D.rowblk && D.waveblk)) {
         if (E.error.empty()) E.error = "uploading a CSR operator failed";

@@ -314,13 +314,99 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(const int *__restrict
 // and gathering x[col]: the k-th entries of 64 consecutive rows of a banded / mesh-ordered operator are neighbours in x, so
 // a gather touches 4-6 lines instead of 12.  Same rounded products, same order of additions.  The diagonal is picked out of
 // the stream (col == row), so diag[] is not read.
-template <int OP, bool NT, int TAG>
-__global__ __launch_bounds__(kBlock) void csr_rowlane_kernel(const int *__restrict__ rowblk, int nblk, int remap,
-                                                              const int *__restrict__ rowptr, const int *__restrict__ col,
-                                                              const double *__restrict__ val, CsrArgs a)
+// The two phases of the row-lane CSR-stream kernels for one row block with <= kStreamNnz entries.  COMP: the block's column
+// indices come as 16-bit deltas (see csr_rowlane_body).  All 256 threads call it (workgroup barrier inside).
+template <bool NT, bool COMP>
+__device__ __forceinline__ void rowlane_stage_sum(int j0, int j1, int s, int e, int row, int cb, const int *__restrict__ col,
+                                                  const unsigned short *__restrict__ col16, const double *__restrict__ val,
+                                                  const double *__restrict__ x, double *sval, int *scol, double &sum, double &dv)
 {
-    __shared__ double sval[kStreamNnz];
-    __shared__ int scol[kStreamNnz];
+    const int tid = threadIdx.x;
+    unsigned short *sc16 = reinterpret_cast<unsigned short *>(scol);
+    // phase 1: the block's col/val run -> LDS, paired loads at even indices (16 B of values with 8 B of indices or 4 B of
+    // deltas; col/val/col16 carry kCsrPad zeroed tail entries)
+    if (j1 > j0) {
+        const int jb = j0 & ~1;
+        const int jlast = (j1 - 1) & ~1;
+        constexpr int U = 4;  // 8 entries per thread in flight: one pass over a full block (measured 4-5 % faster than 2 at 216^3)
+        for (int j = jb + 2 * tid; j < j1; j += 2 * U * kBlock) {
+            i2v c[U];
+            unsigned w[U];
+            d2v v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int jj = j + 2 * u * kBlock;
+                jj = jj < jlast ? jj : jlast;
+                if constexpr (COMP) {
+                    if constexpr (NT) w[u] = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(col16 + jj));
+                    else w[u] = *reinterpret_cast<const unsigned *>(col16 + jj);
+                } else {
+                    if constexpr (NT) c[u] = __builtin_nontemporal_load(reinterpret_cast<const i2v *>(col + jj));
+                    else c[u] = *reinterpret_cast<const i2v *>(col + jj);
+                }
+                if constexpr (NT) v[u] = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(val + jj));
+                else v[u] = *reinterpret_cast<const d2v *>(val + jj);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {  // element-wise LDS writes (whole-pair b64/b128 writes measured 5-8 % slower)
+                const int jj = j + 2 * u * kBlock;
+                if (jj >= j0 && jj < j1) {
+                    if constexpr (COMP) sc16[jj - jb] = (unsigned short)(w[u] & 0xffffu);
+                    else scol[jj - jb] = c[u].x;
+                    sval[jj - jb] = v[u].x;
+                }
+                if (jj + 1 >= j0 && jj + 1 < j1) {
+                    if constexpr (COMP) sc16[jj + 1 - jb] = (unsigned short)(w[u] >> 16);
+                    else scol[jj + 1 - jb] = c[u].y;
+                    sval[jj + 1 - jb] = v[u].y;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // phase 2: lane = row; entries in stored order, eight (col, val) pairs and their gathers in flight at a time
+    int ccur = cb;
+    const int sh = j0 & 1;  // LDS position of entry j0
+    for (int k = s; k < e; k += 8) {
+        int c[8];
+        double v[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kk = (k + u < e ? k + u : e - 1) + sh;
+            if constexpr (COMP) c[u] = (int)sc16[kk];
+            else c[u] = scol[kk];
+            v[u] = sval[kk];
+        }
+        if constexpr (COMP) {  // deltas -> columns: running sum along the row, started at the block's base
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ccur = k + u < e ? ccur + c[u] : ccur;
+                c[u] = ccur;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xv[u] = (k + u < e) ? x[c[u]] : 0.0;  // lanes past their row's end issue no access (ragged rows)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double t = v[u] * xv[u];
+            const bool on = k + u < e;
+            sum = on ? sum + t : sum;
+            dv = (on && c[u] == row) ? v[u] : dv;
+        }
+    }
+}
+
+// C16 (csr_rowlane16_kernel, vec = 4): the column indices of a block travel as 16-bit deltas (DevCsr::col16): the first entry of a
+// row holds col - cbase[block], every further entry col - previous col of its row; phase 2 walks a row in stored order anyway, so
+// the decode is one integer add per entry.  10 instead of 12 bytes per entry; same products, same order of additions.  Blocks a
+// delta does not fit (cbase < 0: a gap >= 65536 inside a row, first columns spread over >= 65536, or one long row) read col[].
+template <int OP, bool NT, bool C16>
+__device__ __forceinline__ void csr_rowlane_body(const int *__restrict__ rowblk, int nblk, int remap, const int *__restrict__ rowptr,
+                                                 const int *__restrict__ col, const unsigned short *__restrict__ col16,
+                                                 const int *__restrict__ cbase, const double *__restrict__ val, const CsrArgs &a)
+{
+    __shared__ __attribute__((aligned(16))) double sval[kStreamNnz + 2];  // + 2: the run is staged from the even index at or below j0
+    __shared__ __attribute__((aligned(16))) int scol[kStreamNnz + 2];
     __shared__ double red[kBlock / 64];
     const int bid = remap ? xcd_remap(blockIdx.x, nblk, remap) : blockIdx.x;
     if (bid >= nblk) return;  // whole workgroup leaves together
@@ -329,6 +415,9 @@ __global__ __launch_bounds__(kBlock) void csr_rowlane_kernel(const int *__restri
     const int r0 = br.x, r1 = br.y;
     const int nrows = r1 - r0;
     const int j0 = br.z, j1 = br.w;
+    int cb = -1;
+    if constexpr (C16) cb = cbase[bid];
+    const bool comp = C16 && cb >= 0;  // workgroup-uniform
     const double *__restrict__ x = a.x;
     const bool has_row = tid < nrows;
     const int row = r0 + tid;
@@ -356,62 +445,9 @@ __global__ __launch_bounds__(kBlock) void csr_rowlane_kernel(const int *__restri
         sum = part;
         store = (tid == 0);
     } else {
-        // phase 1: the block's col/val run -> LDS, paired 8-B / 16-B loads at even indices (col/val carry kCsrPad zeroed tail entries)
-        if (j1 > j0) {
-            const int jb = j0 & ~1;
-            const int jlast = (j1 - 1) & ~1;
-            constexpr int U = 2;
-            for (int j = jb + 2 * tid; j < j1; j += 2 * U * kBlock) {
-                i2v c[U];
-                d2v v[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    int jj = j + 2 * u * kBlock;
-                    jj = jj < jlast ? jj : jlast;
-                    if constexpr (NT) {
-                        c[u] = __builtin_nontemporal_load(reinterpret_cast<const i2v *>(col + jj));
-                        v[u] = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(val + jj));
-                    } else {
-                        c[u] = *reinterpret_cast<const i2v *>(col + jj);
-                        v[u] = *reinterpret_cast<const d2v *>(val + jj);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int jj = j + 2 * u * kBlock;
-                    if (jj >= j0 && jj < j1) {
-                        scol[jj - j0] = c[u].x;
-                        sval[jj - j0] = v[u].x;
-                    }
-                    if (jj + 1 >= j0 && jj + 1 < j1) {
-                        scol[jj + 1 - j0] = c[u].y;
-                        sval[jj + 1 - j0] = v[u].y;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        // phase 2: lane = row; entries in stored order, eight (col, val) pairs and their gathers in flight at a time
         double dv = 0.0;
-        for (int k = s; k < e; k += 8) {
-            int c[8];
-            double v[8], xv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int kk = k + u < e ? k + u : e - 1;
-                c[u] = scol[kk];
-                v[u] = sval[kk];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) xv[u] = (k + u < e) ? x[c[u]] : 0.0;  // lanes past their row's end issue no access (ragged rows)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const double t = v[u] * xv[u];
-                const bool on = k + u < e;
-                sum = on ? sum + t : sum;
-                dv = (on && c[u] == row) ? v[u] : dv;
-            }
-        }
+        if (comp) rowlane_stage_sum<NT, true>(j0, j1, s, e, row, cb, col, col16, val, x, sval, scol, sum, dv);
+        else rowlane_stage_sum<NT, false>(j0, j1, s, e, row, cb, col, col16, val, x, sval, scol, sum, dv);
         o.di = dv;
     }
     double acc = 0.0;
@@ -421,6 +457,23 @@ __global__ __launch_bounds__(kBlock) void csr_rowlane_kernel(const int *__restri
         const double t = block_sum(acc, red);
         if (tid == 0) a.partial[bid] = t;
     }
+}
+
+template <int OP, bool NT, int TAG>
+__global__ __launch_bounds__(kBlock) void csr_rowlane_kernel(const int *__restrict__ rowblk, int nblk, int remap,
+                                                              const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                              const double *__restrict__ val, CsrArgs a)
+{
+    csr_rowlane_body<OP, NT, false>(rowblk, nblk, remap, rowptr, col, nullptr, nullptr, val, a);
+}
+
+template <int OP, bool NT, int TAG>
+__global__ __launch_bounds__(kBlock) void csr_rowlane16_kernel(const int *__restrict__ rowblk, int nblk, int remap,
+                                                                const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                                const unsigned short *__restrict__ col16, const int *__restrict__ cbase,
+                                                                const double *__restrict__ val, CsrArgs a)
+{
+    csr_rowlane_body<OP, NT, true>(rowblk, nblk, remap, rowptr, col, col16, cbase, val, a);
 }
 
 template <int OP, bool NT, int VEC, int TAG>
@@ -1339,6 +1392,13 @@ int launch_csr_tagged(const DevCsr &A, const CsrArgs &a, bool nt, int remap, hip
     }
     if (A.nblk <= 0) return 0;
     const int grid = remap_grid(A.nblk, remap);
+    if (fam == FAM_CSR_ROWLANE16) {  // row-lane order, 16-bit delta-coded column indices
+        if (nt)
+            hipLaunchKernelGGL((csr_rowlane16_kernel<OP, true, TAG>), dim3(grid), dim3(kBlock), 0, st, A.rowblk, A.nblk, remap, A.rowptr, A.col, A.col16, A.cbase, A.val, a);
+        else
+            hipLaunchKernelGGL((csr_rowlane16_kernel<OP, false, TAG>), dim3(grid), dim3(kBlock), 0, st, A.rowblk, A.nblk, remap, A.rowptr, A.col, A.col16, A.cbase, A.val, a);
+        return A.nblk;
+    }
     if (fam == FAM_CSR_ROWLANE) {  // gathers in row-lane order (col/val staged in LDS)
         if (nt)
             hipLaunchKernelGGL((csr_rowlane_kernel<OP, true, TAG>), dim3(grid), dim3(kBlock), 0, st, A.rowblk, A.nblk, remap, A.rowptr, A.col, A.val, a);
@@ -1369,7 +1429,9 @@ CsrFamily csr_family(const DevCsr &A, const KernelConfig &c)
     if (c.kind == 1 && A.waveblk) return FAM_CSR_WAVE;
     // workgroup CSR-stream kernels: gathers in row-lane order when asked for, or (vec = 3) when the operator streams from HBM
     const size_t csr_bytes = (size_t)A.nnz * 12 + (size_t)A.nrow * 36;
-    if (c.vec == 2 || (c.vec == 3 && csr_bytes > (240u << 20))) return FAM_CSR_ROWLANE;
+    const bool streams = csr_bytes > (240u << 20);
+    if ((c.vec == 4 || (c.vec == 3 && streams)) && A.col16) return FAM_CSR_ROWLANE16;  // 10 instead of 12 bytes per entry
+    if (c.vec == 2 || c.vec == 4 || (c.vec == 3 && streams)) return FAM_CSR_ROWLANE;
     return FAM_CSR_BLOCK;
 }
 
@@ -1398,6 +1460,7 @@ const char *csr_family_name(CsrFamily f)
     case FAM_SELL: return "sell_kernel";
     case FAM_CSR_WAVE: return "csr_wave_kernel";
     case FAM_CSR_ROWLANE: return "csr_rowlane_kernel";
+    case FAM_CSR_ROWLANE16: return "csr_rowlane16_kernel";
     default: return "csr_block_kernel";
     }
 }
@@ -1828,6 +1891,39 @@ std::vector<int> rowblock_records(int nrow, const int *rowptr, int *nblk)
     }
     *nblk = nb;
     return rec;
+}
+
+int build_col16(const int *rowptr, const int *col, const int *rec, int nblk, unsigned short *col16, int *cbase)
+{
+    int n16 = 0;
+#pragma omp parallel for schedule(static) reduction(+ : n16)
+    for (int k = 0; k < nblk; ++k) {
+        const int r0 = rec[(size_t)4 * k], r1 = rec[(size_t)4 * k + 1];
+        const int j0 = rec[(size_t)4 * k + 2], j1 = rec[(size_t)4 * k + 3];
+        bool fits = !(r1 - r0 == 1 && j1 - j0 > kStreamNnz) && j1 > j0;  // a long row is summed with strided accesses: keeps col[]
+        int base = 0x7fffffff, top = -1;
+        for (int r = r0; fits && r < r1; ++r) {
+            const int s = rowptr[r], e = rowptr[r + 1];
+            if (s == e) continue;
+            base = std::min(base, col[s]);
+            top = std::max(top, col[s]);
+            for (int j = s + 1; j < e; ++j) {
+                const long d = (long)col[j] - col[j - 1];
+                if (d < 0 || d > 65535) fits = false;  // unsorted row or a gap too wide
+            }
+        }
+        if (fits && (top < 0 || (long)top - base > 65535)) fits = false;
+        for (int j = j0; j < j1; ++j) col16[j] = 0;
+        cbase[k] = -1;
+        if (!fits) continue;
+        cbase[k] = base;
+        ++n16;
+        for (int r = r0; r < r1; ++r) {
+            const int s = rowptr[r], e = rowptr[r + 1];
+            for (int j = s; j < e; ++j) col16[j] = (unsigned short)(j == s ? col[j] - base : col[j] - col[j - 1]);
+        }
+    }
+    return n16;
 }
 
 int build_waveblocks(int nrow, const int *rowptr, int *out)

@@ -27,6 +27,12 @@ struct DevCsr {
     // entry, end entry} (16-byte aligned); nnz of a block <= kStreamNnz unless it is a single long row
     int *rowblk = nullptr;
     int nblk = 0;
+    // optional compressed column indices of the row blocks (csr_rowlane16_kernel): 16-bit deltas -- first entry of a row
+    // relative to cbase[block], further entries relative to the previous column of the row; cbase[block] = -1 where a
+    // delta does not fit (that block reads col[])
+    unsigned short *col16 = nullptr;
+    int *cbase = nullptr;
+    int nblk16 = 0;  // blocks that use the 16-bit form
     // wave-granular schedule: wave-block k owns rows [waveblk[k], waveblk[k+1]) (<= 64 rows,
     // <= kWaveNnz products unless it is a single long row)
     int *waveblk = nullptr;
@@ -80,18 +86,21 @@ struct KernelConfig {
                         // back (3 -> 2 -> 0) where the operator does not qualify for the mirror
     int vec = 3;        // CSR-stream kernels: 0 one entry per load, 1 two entries per lane (16-B val / 8-B col loads), 2 (workgroup kernel)
                         // col/val staged in LDS and the x gathers issued in row-lane order (csr_rowlane_kernel), 3 = 2 for operators
-                        // that stream from HBM (> 240 MB of CSR bytes), 1 below (a cache-resident ragged operator is faster on 1)
+                        // that stream from HBM (> 240 MB of CSR bytes), 1 below (a cache-resident ragged operator is faster on 1);
+                        // 4 = 2 with 16-bit delta-coded column indices where the operator carries them (csr_rowlane16_kernel)
     bool auto_policy = true;  // choose nt / remap per operator from its size (overrides the two below)
     bool nt = true;     // non-temporal loads for the matrix stream
     int remap = 1;      // 0 none, 1 XCD x owns the x-th contiguous eighth, G>1 groups of G row blocks dealt round-robin to XCDs
     bool table = true;  // use the level-wide stencil table where a level has one
     bool tile = false;  // table levels of grid stencils: stage x tiles in LDS (sdia_tile_kernel) on whole-level launches
     bool const_slots = true;  // layout option read at setup: fold constant diagonals of a slice into one scalar
+    int idx16 = 1;      // layout option read at setup: build the 16-bit delta column form (DevCsr::col16) for 0 no operator,
+                        // 1 operators whose default family is the CSR-stream kernel streaming from HBM, 2 every operator
 };
 
 // which kernel a launch of launch_csr on operator A runs under cfg (one decision, used by the
 // launcher and by every report of it)
-enum CsrFamily : int { FAM_CSR_BLOCK = 0, FAM_CSR_WAVE = 1, FAM_SELL = 2, FAM_SDIA = 3, FAM_SDIA_TAB = 4, FAM_CSR_ROWLANE = 5 };
+enum CsrFamily : int { FAM_CSR_BLOCK = 0, FAM_CSR_WAVE = 1, FAM_SELL = 2, FAM_SDIA = 3, FAM_SDIA_TAB = 4, FAM_CSR_ROWLANE = 5, FAM_CSR_ROWLANE16 = 6 };
 
 constexpr int kBlock = 256;       // threads per workgroup (4 waves)
 constexpr int kStreamNnz = 2048;  // products staged in LDS per workgroup (16 KiB)
@@ -132,6 +141,9 @@ int build_rowblocks(int nrow, const int *rowptr, int *out);
 int build_waveblocks(int nrow, const int *rowptr, int *out);
 // the row-block schedule as the 4-int records DevCsr::rowblk holds (4 * *nblk ints)
 std::vector<int> rowblock_records(int nrow, const int *rowptr, int *nblk);
+// 16-bit delta form of the column indices for the row blocks `rec` (DevCsr::col16 / cbase); col16 holds nnz entries,
+// cbase nblk; returns the number of blocks that took the 16-bit form
+int build_col16(const int *rowptr, const int *col, const int *rec, int nblk, unsigned short *col16, int *cbase);
 
 // returns the number of per-workgroup partial sums the launch writes (reducing ops)
 // `finest`: launch on the finest level (selects a separately named kernel instance for profilers)

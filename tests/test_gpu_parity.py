@@ -34,7 +34,9 @@ CASES = {
 @pytest.fixture(scope="module", params=list(CASES))
 def case(request):
     rp, ci, v = CASES[request.param]()
-    A, O = _mk(rp, ci, v)
+    # every operator also carries its 16-bit delta-coded column indices (only the (0, 4) family below reads them)
+    A = sa.sp_matrix_mg(rp, ci, v).set_index_compression(2).setup(sa.default_params(**QUIET))
+    O = oracle.Csr(rp, ci, v)
     H = oracle.Hierarchy(O)
     return request.param, A, O, H
 
@@ -68,7 +70,8 @@ def test_kernels_bitwise(case):
     assert np.linalg.norm(xg - xo) <= 1e-10 * np.linalg.norm(xo)
 
 
-KERNEL_CONFIGS = [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (2, 0), (3, 0)]  # (0, 2): CSR-stream with row-lane gathers
+# (0, 2): CSR-stream with row-lane gathers; (0, 4): the same with 16-bit delta-coded column indices
+KERNEL_CONFIGS = [(0, 0), (0, 1), (0, 2), (0, 4), (1, 0), (1, 1), (2, 0), (3, 0)]
 
 
 @pytest.mark.parametrize("kind,vec", KERNEL_CONFIGS)
@@ -80,6 +83,8 @@ def test_kernel_families_bitwise(case, kind, vec):
     try:
         for nt, remap in ((1, 1), (0, 0), (1, 16), (-1, -1)):
             A.set_kernel_config(kind=kind, vec=vec, nt=nt, remap=remap)
+            if (kind, vec) == (0, 4):
+                assert A.level_kernel(0) == "csr_rowlane16_kernel" and A.level_index16(0)[0] > 0
             for l in range(A.nlevels):
                 n = A.level_info(l)["nrow"]
                 x = rng.standard_normal(n)
@@ -246,6 +251,70 @@ def test_beck_coarsening():
     xo, ho = H.solve(b)
     _hist_ok(h, ho)
     assert np.linalg.norm(x - xo) <= 1e-8 * np.linalg.norm(xo)
+
+
+def test_index16_blocks_and_fallbacks():
+    """16-bit delta-coded column indices (SURVEY 8f-4 'compressed indices'): blocks whose deltas fit use them, blocks with a gap
+    of 65536 or more, an unsorted row or one over-long row keep col[]; general P / R (Beck) go through the same kernel.
+    Everything bitwise against the oracle."""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(21)
+    n = 150000
+    M = sp.diags([np.full(n - 1, -1.0), np.full(n, 4.0), np.full(n - 1, -1.0)], [-1, 0, 1], format="lil")
+    M[5, 70000] = 0.5        # gap of 69994 inside row 5 -> its block keeps 32-bit indices
+    M[70000, 5] = 0.5
+    M[3000, 3000 + 65535] = 0.25   # the largest gap that still fits (65534 after the +1 neighbour)
+    M[90000, :4000] = rng.standard_normal(4000)  # one row longer than the LDS buffer
+    M = M.tocsr()
+    M.sort_indices()
+    A = sa.sp_matrix_mg(M.indptr, M.indices, M.data).set_index_compression(2).setup(sa.default_params(**QUIET, limit_upper=200000))
+    assert A.nlevels == 1
+    b16, nb = A.level_index16(0)
+    assert 0 < b16 < nb and nb - b16 <= 8, (b16, nb)   # a handful of blocks fall back
+    Mo = oracle.Csr(M.indptr, M.indices, M.data)
+    x = rng.standard_normal(n)
+    b = rng.standard_normal(n)
+    A.set_kernel_config(kind=0, vec=4)
+    assert A.level_kernel(0) == "csr_rowlane16_kernel"
+    mask = np.ones(n, bool)
+    mask[90000] = False  # the long row is tree-summed (tolerance), everything else in stored order (bitwise)
+    yo = oracle.spmv(Mo, x)
+    y = A.op_spmv(0, x)
+    assert np.array_equal(y[mask], yo[mask])
+    assert abs(y[90000] - yo[90000]) <= 1e-12 * (np.abs(M[90000].toarray()).ravel() @ np.abs(x))
+    ro = oracle.store_residual(Mo, b, x)
+    assert np.array_equal(A.op_residual(0, b, x)[mask], ro[mask])
+    jo = oracle.jacobi(Mo, b, x, 0)
+    assert np.array_equal(A.op_jacobi(0, b, x, 1)[mask], jo[mask])
+    A.close()
+    # mode 0 builds nothing and vec = 4 then runs the 32-bit row-lane kernel; mode 1 leaves small operators alone
+    rp, ci, v = problems.poisson3d(30)
+    for mode in (0, 1):
+        B = sa.sp_matrix_mg(rp, ci, v).set_index_compression(mode).setup(sa.default_params(**QUIET))
+        B.set_kernel_config(kind=0, vec=4)
+        assert B.level_index16(0)[0] == 0 and B.level_kernel(0) == "csr_rowlane_kernel"
+        B.close()
+    # Beck: multi-entry P and R through the compressed kernel, whole solve equal to the default family's
+    C1 = sa.sp_matrix_mg(rp, ci, v).set_index_compression(2).setup(sa.default_params(**QUIET, coarsening=1))
+    H = oracle.Hierarchy(oracle.Csr(rp, ci, v), oracle.params(coarsening=1))
+    C1.set_kernel_config(kind=0, vec=4)
+    for l in range(C1.nlevels - 1):
+        nf = C1.level_info(l)["nrow"]
+        nc = C1.level_info(l + 1)["nrow"]
+        xf = rng.standard_normal(nf)
+        xc = rng.standard_normal(nc)
+        assert np.array_equal(C1.op_restrict(l, xf), oracle.transfer_residual(H.P(l), xf)), l
+        assert np.array_equal(C1.op_prolong(l, xc, xf), oracle.transfer_solution(H.P(l), xc, xf)), l
+        assert np.array_equal(C1.op_spmv(l, xf), oracle.spmv(H.A(l), xf)), l
+    bb = np.ones(C1.nrow)
+    x1 = np.zeros(C1.nrow)
+    h1, _ = C1.solve("pcg", bb, x1)
+    C1.set_kernel_config()
+    x0 = np.zeros(C1.nrow)
+    h0, _ = C1.solve("pcg", bb, x0)
+    assert np.array_equal(h0, h1) and np.array_equal(x0, x1)
+    C1.close()
 
 
 def test_edge_cases():

@@ -36,6 +36,7 @@ def main():
     A = sa.sp_matrix_mg(rp, ci, v)
     if a.no_const:
         A.set_const_slots(False)
+    A.set_index_compression(2)  # every operator also carries 16-bit delta-coded column indices (read by vec = 4 only)
     A.setup(sa.default_params(print_setup=0, print_solve=0))
     if a.cfg:
         A.set_kernel_config(*a.cfg)
@@ -58,7 +59,7 @@ def main():
         return
     if a.variants:
         print(f"{'config':28s} {'op':8s} {'lvl':>3s} {'us':>9s} {'GB/s':>8s} {'frac8T':>7s}")
-        cfgs = [(k, v, nt, rm) for k in a.kinds for v in ((0, 1, 2) if k == 0 else ((0, 1) if k == 1 else (0,))) for nt in (1, 0) for rm in (1, 16)]
+        cfgs = [(k, v, nt, rm) for k in a.kinds for v in ((0, 1, 2, 4) if k == 0 else ((0, 1) if k == 1 else (0,))) for nt in (1, 0) for rm in (1, 16)]
         for rnd in range(a.rounds):
             for (k, v, nt, rm) in cfgs:
                 A.set_kernel_config(kind=k, vec=v, nt=nt, remap=rm)
