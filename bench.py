@@ -576,6 +576,9 @@ def main():
                     f"(sweeps+1 ghost layers per block, ONE ghost-layer exchange per smoothing leg, grouped ncclSend/ncclRecv of packed "
                     f"buffers: {exchanges_per_step:.1f} transport calls per iteration), 16-byte ncclAllReduce per fused scalar, coarser levels replicated")),
                 "transport_calls_per_iteration": round(exchanges_per_step, 2) if mode == "partitioned" else None,
+                "hierarchy_setup": (None if mode != "partitioned" else
+                                    (lambda bi: f"rank 0 ran the host setup, {bi[1] / 1e6:.0f} MB hierarchy image broadcast to the other ranks (ncclBroadcast)"
+                                     if bi[1] > 0 else "every rank ran the host setup itself")(A.setup_share_info())),
                 "multi_gpu_parity": parity,
                 "algorithmic_GB_per_iteration": round(it_bytes / 1e9, 3),
                 "solve_GBps": round(it_bytes * its_per_s / 1e9, 1),

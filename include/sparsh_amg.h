@@ -142,6 +142,18 @@ int sparsh_set_const_slots(sparsh_handle h, int enable);
  * 2 for every operator (A/B measurements with sparsh_set_kernel_config(h, 0, 4, ...)).
  * sparsh_level_index16: how many row blocks of a level's operator use the 16-bit form, out of how many. */
 int sparsh_set_index_compression(sparsh_handle h, int mode);
+/* Multi-GPU setup: by default rank 0 alone runs the host setup (coarsening, Galerkin products, coarse factor) and the other
+ * ranks receive the finished hierarchy through the transport (one RCCL broadcast of its byte image, staged through HBM in
+ * 256 MB pieces) instead of repeating the identical setup N times; every rank then cuts out and uploads its own row
+ * blocks as before.  sparsh_set_setup_broadcast(h, 0) before sparsh_setup: every rank builds its own copy (round-1
+ * behaviour; the hierarchies are identical either way -- the setup is deterministic).  Collective: all ranks must use
+ * the same setting.  sparsh_setup_share_info: whether this rank built the hierarchy itself, and the image size in bytes
+ * (0 when nothing was broadcast). */
+int sparsh_set_setup_broadcast(sparsh_handle h, int enable);
+int sparsh_setup_share_info(sparsh_handle h, int *built_locally, long *image_bytes);
+/* Test hook (host only, after sparsh_setup_host): writes the byte image, reads it back (only the first truncate_to bytes when
+ * truncate_to >= 0) and compares every array of the two hierarchies; returns the image size or a negative SPARSH_E*. */
+long sparsh_debug_hierarchy_roundtrip(sparsh_handle h, long truncate_to);
 int sparsh_level_index16(sparsh_handle h, int level, long *blocks16, long *blocks);
 /* Table levels of grid stencils (offsets -1, 0, +1, +-line[, +-plane]) run, on whole-level launches, a
  * variant that stages x[r0 - line, r0 + T + line) of every workgroup's T rows in LDS, so the centre, +-1 and

@@ -88,6 +88,9 @@ def _load():
         "sparsh_set_const_slots": (C.c_int, [H, C.c_int]),
         "sparsh_set_tile": (C.c_int, [H, C.c_int]),
         "sparsh_set_index_compression": (C.c_int, [H, C.c_int]),
+        "sparsh_set_setup_broadcast": (C.c_int, [H, C.c_int]),
+        "sparsh_debug_hierarchy_roundtrip": (C.c_long, [H, C.c_long]),
+        "sparsh_setup_share_info": (C.c_int, [H, C.POINTER(C.c_int), C.POINTER(C.c_long)]),
         "sparsh_level_index16": (C.c_int, [H, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
         "sparsh_level_tile_rows": (C.c_int, [H, C.c_int, c_int_p]),
         "sparsh_bench_comm": (C.c_int, [H, C.c_int, C.c_int, C.c_int, c_dbl_p]),
@@ -250,6 +253,24 @@ class sp_matrix_mg:
         """Layout option read by setup(): fold constant diagonals of a slice into one scalar."""
         _check(lib.sparsh_set_const_slots(self._h, int(bool(enable))))
         return self
+
+    def set_setup_broadcast(self, enable=True):
+        """Multi-GPU: rank 0 builds the hierarchy and broadcasts it (default) / every rank builds its own; before setup."""
+        _check(lib.sparsh_set_setup_broadcast(self._h, int(bool(enable))))
+        return self
+
+    def hierarchy_roundtrip(self, truncate_to=-1):
+        """Test hook: hierarchy -> byte image -> hierarchy, compared array by array; returns the image size."""
+        r = lib.sparsh_debug_hierarchy_roundtrip(self._h, int(truncate_to))
+        if r < 0:
+            _check(int(r))
+        return int(r)
+
+    def setup_share_info(self):
+        """(this rank ran the host setup itself, bytes of the broadcast hierarchy image)."""
+        a, b = C.c_int(), C.c_long()
+        _check(lib.sparsh_setup_share_info(self._h, C.byref(a), C.byref(b)))
+        return bool(a.value), b.value
 
     def set_index_compression(self, mode=1):
         """16-bit delta-coded column indices for the CSR-stream family (call before setup); see sparsh_set_index_compression."""

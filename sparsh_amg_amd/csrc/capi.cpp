@@ -300,6 +300,48 @@ int sparsh_set_const_slots(sparsh_handle h, int enable)
     return SPARSH_OK;
 }
 
+int sparsh_set_setup_broadcast(sparsh_handle h, int enable)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    h->eng->set_share_setup(enable != 0);
+    return SPARSH_OK;
+}
+
+int sparsh_setup_share_info(sparsh_handle h, int *built_locally, long *image_bytes)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    if (built_locally) *built_locally = h->eng->built_locally() ? 1 : 0;
+    if (image_bytes) *image_bytes = (long)h->eng->shared_image_bytes();
+    return SPARSH_OK;
+}
+
+// test hook (host only): byte image of the hierarchy -> fresh hierarchy -> compare every array; returns the image size
+long sparsh_debug_hierarchy_roundtrip(sparsh_handle h, long truncate_to)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    if (!h->eng->host_ready()) return fail(SPARSH_ESTATE, "sparsh_setup_host has not been called");
+    const HostHierarchy &H = h->eng->host();
+    std::vector<char> img;
+    serialize_hierarchy(H, img);
+    HostHierarchy G;
+    const size_t use = truncate_to >= 0 ? std::min<size_t>((size_t)truncate_to, img.size()) : img.size();
+    if (!deserialize_hierarchy(img.data(), use, H.levels[0].A, G)) return fail(SPARSH_EINVAL, G.error);
+    const auto same_csr = [](const HostCsr &a, const HostCsr &b) {
+        if (a.nrow != b.nrow || a.ncol != b.ncol || a.nnz() != b.nnz()) return false;
+        if (!a.rowptr) return !b.rowptr;
+        const size_t nnz = (size_t)a.nnz();
+        return std::memcmp(a.rowptr, b.rowptr, ((size_t)a.nrow + 1) * sizeof(int)) == 0 && std::memcmp(a.col, b.col, nnz * sizeof(int)) == 0 &&
+               std::memcmp(a.val, b.val, nnz * sizeof(double)) == 0;
+    };
+    bool same = G.levels.size() == H.levels.size() && G.nL == H.nL && G.coarse_dense == H.coarse_dense && G.extended == H.extended &&
+                G.coarse_inverse == H.coarse_inverse;
+    for (size_t l = 0; same && l < H.levels.size(); ++l)
+        same = same_csr(G.levels[l].A, H.levels[l].A) && same_csr(G.levels[l].P, H.levels[l].P) && same_csr(G.levels[l].R, H.levels[l].R) &&
+               G.levels[l].diag == H.levels[l].diag && G.levels[l].P_is_aggregation == H.levels[l].P_is_aggregation;
+    if (!same) return fail(SPARSH_ENUMERIC, "hierarchy image round trip changed the hierarchy");
+    return (long)img.size();
+}
+
 int sparsh_set_index_compression(sparsh_handle h, int mode)
 {
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");

@@ -20,6 +20,7 @@ public:
     bool allreduce_sum(double *, int, hipStream_t) override { return true; }
     bool allgather(double *, const Partition &, hipStream_t) override { return true; }
     bool barrier(hipStream_t) override { return true; }
+    bool bcast(void *, size_t, int, hipStream_t) override { return true; }
 };
 }  // namespace
 
@@ -96,6 +97,10 @@ public:
         (void)hipMemsetAsync(scratch, 0, sizeof(double), st);
         if (!allreduce_sum(scratch, 1, st)) return false;
         return hipStreamSynchronize(st) == hipSuccess;
+    }
+    bool bcast(void *dev, size_t bytes, int root, hipStream_t st) override
+    {
+        return ok(ncclBroadcast(dev, dev, bytes, ncclChar, root, comm, st), "ncclBroadcast");
     }
     double *scratch = nullptr;
 };
@@ -315,6 +320,16 @@ public:
     {
         (void)hipStreamSynchronize(st);
         g->wait();
+        return true;
+    }
+    bool bcast(void *dev, size_t bytes, int root, hipStream_t st) override
+    {
+        (void)hipStreamSynchronize(st);  // the root's buffer is complete before anyone reads it
+        g->ptrs[rank] = static_cast<double *>(dev);
+        g->wait();
+        if (rank != root && bytes > 0) (void)hipMemcpyAsync(dev, g->ptrs[root], bytes, hipMemcpyDeviceToDevice, st);
+        (void)hipStreamSynchronize(st);
+        g->wait();  // the root may reuse its buffer only after every pull has finished
         return true;
     }
 };

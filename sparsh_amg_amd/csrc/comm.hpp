@@ -53,6 +53,8 @@ public:
     // every rank contributes full[lo(rank) .. hi(rank)) of `part`; afterwards all ranks hold all of it
     virtual bool allgather(double *full, const Partition &part, hipStream_t st) = 0;
     virtual bool barrier(hipStream_t st) = 0;
+    // bytes of device memory from rank `root` to the same buffer on every rank (setup: the hierarchy image)
+    virtual bool bcast(void *dev, size_t bytes, int root, hipStream_t st) = 0;
     std::string error;
 };
 

@@ -486,6 +486,70 @@ int Engine::setup_host(const sparsh_params &p)
     return SPARSH_OK;
 }
 
+int Engine::setup_host_shared(const sparsh_params &p)
+{
+    const int me = comm_->rank;
+    const double t0 = omp_get_wtime();
+    std::vector<char> image;
+    int rc0 = SPARSH_OK;
+    std::string err0;
+    if (me == 0) {
+        rc0 = setup_host(p);
+        err0 = error;
+        if (rc0 == SPARSH_OK) serialize_hierarchy(H_, image);
+    }
+    built_locally_ = (me == 0);
+    // header: image size and rank 0's return code (every rank takes part in both broadcasts, also after a failed setup)
+    long long *hdr = nullptr;
+    if (!check(hipMalloc(reinterpret_cast<void **>(&hdr), 16), "hipMalloc")) return SPARSH_ENODEV;
+    long long h2[2] = {(long long)image.size(), (long long)rc0};
+    bool good = check(hipMemcpyAsync(hdr, h2, 16, hipMemcpyHostToDevice, st_), "hipMemcpy");
+    good = good && comm_->bcast(hdr, 16, 0, st_);
+    good = good && check(hipMemcpyAsync(h2, hdr, 16, hipMemcpyDeviceToHost, st_), "hipMemcpy") && check(hipStreamSynchronize(st_), "hipStreamSynchronize");
+    (void)hipFree(hdr);
+    if (!good) {
+        if (error.empty()) error = "broadcast of the hierarchy header failed: " + comm_->error;
+        return SPARSH_ECOMM;
+    }
+    if (h2[1] != SPARSH_OK) {
+        error = me == 0 ? err0 : "the setup on rank 0 failed";
+        host_ready_ = false;
+        return (int)h2[1];
+    }
+    const size_t total = (size_t)h2[0];
+    image_bytes_ = total;
+    if (me != 0) image.resize(total);
+    // the image travels through one device staging buffer, chunk by chunk
+    const size_t chunk = std::min<size_t>(total, (size_t)256 << 20);
+    char *stage = nullptr;
+    if (chunk > 0 && !check(hipMalloc(reinterpret_cast<void **>(&stage), chunk), "hipMalloc")) return SPARSH_ENODEV;
+    for (size_t off = 0; good && off < total; off += chunk) {
+        const size_t nb = std::min(chunk, total - off);
+        if (me == 0) good = check(hipMemcpyAsync(stage, image.data() + off, nb, hipMemcpyHostToDevice, st_), "hipMemcpy");
+        good = good && comm_->bcast(stage, nb, 0, st_);
+        if (good && me != 0) good = check(hipMemcpyAsync(image.data() + off, stage, nb, hipMemcpyDeviceToHost, st_), "hipMemcpy");
+        good = good && check(hipStreamSynchronize(st_), "hipStreamSynchronize");
+    }
+    if (stage) (void)hipFree(stage);
+    if (!good) {
+        if (error.empty()) error = "broadcast of the hierarchy failed: " + comm_->error;
+        return SPARSH_ECOMM;
+    }
+    if (me != 0) {
+        prm_ = p;
+        ready_ = false;
+        if (!deserialize_hierarchy(image.data(), image.size(), A0_, H_)) {
+            error = H_.error;
+            host_ready_ = false;
+            return SPARSH_ENUMERIC;
+        }
+        host_ready_ = true;
+        setup_seconds = omp_get_wtime() - t0;
+        H_.seconds = setup_seconds;
+    }
+    return SPARSH_OK;
+}
+
 bool Engine::upload_plan(const HaloPlan &h, DevPlan &d)
 {
     d.nloc = h.nloc;
@@ -581,7 +645,9 @@ int Engine::setup(const sparsh_params &p)
 
     sparsh_params hp = p;
     if (G > 1 && me != 0) hp.print_setup = 0;  // one copy of the "Level k:" lines
-    if (int rc = setup_host(hp); rc != SPARSH_OK) return rc;
+    built_locally_ = true;
+    image_bytes_ = 0;
+    if (int rc = (G > 1 && share_setup_) ? setup_host_shared(hp) : setup_host(hp); rc != SPARSH_OK) return rc;
     prm_ = p;
 
     // ---- row partition of every level (multi-GPU).  Levels at or below replicate_rows, and always

@@ -81,6 +81,12 @@ public:
     ~Engine();
 
     int setup_host(const sparsh_params &p);  // hierarchy on the host only (no device needed)
+    // multi-GPU: rank 0 runs setup_host and the other ranks receive its hierarchy through the transport instead of
+    // repeating the same setup (set_share_setup(false): every rank builds its own, as in round 1)
+    int setup_host_shared(const sparsh_params &p);
+    void set_share_setup(bool on) { share_setup_ = on; }
+    bool built_locally() const { return built_locally_; }
+    size_t shared_image_bytes() const { return image_bytes_; }
     int setup(const sparsh_params &p);       // setup_host + upload to HBM
     bool ready() const { return ready_; }
     bool host_ready() const { return host_ready_; }
@@ -217,6 +223,8 @@ private:
     hipStream_t st_ = nullptr;
     bool ready_ = false;
     bool host_ready_ = false;
+    bool share_setup_ = true, built_locally_ = true;
+    size_t image_bytes_ = 0;
     int fault_ = 0;
     int device_ = 0;
 

@@ -608,4 +608,132 @@ bool build_hierarchy(const HostCsr &A0, const SetupParams &prm, HostHierarchy &H
     return true;
 }
 
+// ---------------------------------------------------------------- byte image of a hierarchy
+namespace {
+constexpr uint64_t kImageMagic = 0x3152454948525053ull;  // "SPRHIER1"
+struct ImageWriter {
+    std::vector<char> &o;
+    void raw(const void *p, size_t n)
+    {
+        const size_t at = o.size();
+        o.resize(at + n);
+        if (n) std::memcpy(o.data() + at, p, n);
+    }
+    void u64(uint64_t v) { raw(&v, sizeof v); }
+    template <class T>
+    void vec(const T *p, size_t n)
+    {
+        u64(n);
+        raw(p, n * sizeof(T));
+    }
+    void csr(const HostCsr &A)
+    {
+        u64((uint64_t)A.nrow);
+        u64((uint64_t)A.ncol);
+        const size_t nnz = (size_t)A.nnz();
+        vec(A.rowptr, A.rowptr ? (size_t)A.nrow + 1 : 0);
+        vec(A.col, nnz);
+        vec(A.val, nnz);
+    }
+};
+struct ImageReader {
+    const char *p, *end;
+    bool ok = true;
+    bool raw(void *dst, size_t n)
+    {
+        if (!ok || (size_t)(end - p) < n) return ok = false;
+        if (n) std::memcpy(dst, p, n);
+        p += n;
+        return true;
+    }
+    uint64_t u64()
+    {
+        uint64_t v = 0;
+        raw(&v, sizeof v);
+        return v;
+    }
+    template <class T>
+    bool vec(std::vector<T> &v)
+    {
+        const uint64_t n = u64();
+        if (!ok || n > (uint64_t)(end - p) / sizeof(T)) return ok = false;
+        v.resize((size_t)n);
+        return raw(v.data(), (size_t)n * sizeof(T));
+    }
+    bool csr(HostCsr &A)
+    {
+        A = HostCsr();
+        A.nrow = (int)u64();
+        A.ncol = (int)u64();
+        if (!vec(A.rp_store) || !vec(A.col_store) || !vec(A.val_store)) return false;
+        if (A.rp_store.empty()) return ok;  // an absent operator (P / R of the last level)
+        if (A.rp_store.size() != (size_t)A.nrow + 1 || (size_t)A.rp_store.back() != A.col_store.size() ||
+            A.col_store.size() != A.val_store.size())
+            return ok = false;
+        A.adopt();
+        return true;
+    }
+};
+}  // namespace
+
+void serialize_hierarchy(const HostHierarchy &H, std::vector<char> &out)
+{
+    out.clear();
+    ImageWriter w{out};
+    w.u64(kImageMagic);
+    w.u64(H.levels.size());
+    w.u64((uint64_t)H.nL);
+    w.u64(H.coarse_dense ? 1 : 0);
+    w.u64(H.extended ? 1 : 0);
+    for (size_t l = 0; l < H.levels.size(); ++l) {
+        const HostLevel &L = H.levels[l];
+        if (l > 0) w.csr(L.A);
+        w.csr(L.P);
+        w.csr(L.R);
+        w.vec(L.diag.data(), L.diag.size());
+        w.u64(L.P_is_aggregation ? 1 : 0);
+    }
+    w.vec(H.coarse_inverse.data(), H.coarse_inverse.size());
+}
+
+bool deserialize_hierarchy(const char *buf, size_t bytes, const HostCsr &A0, HostHierarchy &H)
+{
+    H = HostHierarchy();
+    ImageReader r{buf, buf + bytes};
+    if (r.u64() != kImageMagic) {
+        H.error = "hierarchy image: bad magic";
+        return false;
+    }
+    const uint64_t nl = r.u64();
+    H.nL = (int)r.u64();
+    H.coarse_dense = r.u64() != 0;
+    H.extended = r.u64() != 0;
+    if (!r.ok || nl == 0 || nl > 64) {
+        H.error = "hierarchy image: bad header";
+        return false;
+    }
+    H.levels.resize((size_t)nl);
+    for (size_t l = 0; l < (size_t)nl; ++l) {
+        HostLevel &L = H.levels[l];
+        if (l == 0)
+            L.A = HostCsr::alias(A0.nrow, A0.ncol, A0.rowptr, A0.col, A0.val);
+        else
+            r.csr(L.A);
+        r.csr(L.P);
+        r.csr(L.R);
+        r.vec(L.diag);
+        L.P_is_aggregation = r.u64() != 0;
+        if (!r.ok || (size_t)L.A.nrow != L.diag.size()) {
+            H.error = "hierarchy image: truncated or inconsistent level";
+            return false;
+        }
+    }
+    r.vec(H.coarse_inverse);
+    if (!r.ok || r.p != r.end || H.levels.back().A.nrow != H.nL) {
+        H.error = "hierarchy image: truncated";
+        return false;
+    }
+    return true;
+}
+
 }  // namespace sparsh

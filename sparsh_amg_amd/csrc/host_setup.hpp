@@ -94,4 +94,9 @@ bool sparse_inverse(const HostCsr &A, std::vector<double> &inv);
 // whole setup
 bool build_hierarchy(const HostCsr &A0, const SetupParams &prm, HostHierarchy &H);
 
+// Flat byte image of a hierarchy (multi-GPU: rank 0 builds it once, the other ranks receive it instead of repeating
+// the setup).  Level 0's operator is not part of the image: every rank aliases the caller's arrays, as build_hierarchy does.
+void serialize_hierarchy(const HostHierarchy &H, std::vector<char> &out);
+bool deserialize_hierarchy(const char *buf, size_t bytes, const HostCsr &A0, HostHierarchy &H);
+
 }  // namespace sparsh

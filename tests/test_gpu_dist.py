@@ -99,6 +99,54 @@ def test_virtual_ranks_match_single_rank(name, G):
         assert np.linalg.norm(x - x1) <= 1e-8 * np.linalg.norm(x1)
 
 
+def test_hierarchy_broadcast_from_rank0():
+    """Multi-GPU setup: rank 0 builds the hierarchy once and the others receive its byte image through the transport; the
+    partitioned solve is bit for bit the one obtained when every rank runs the whole setup itself."""
+    for gen, kw in ((lambda: problems.poisson3d(30), dict(replicate_rows=2000)),
+                    (lambda: problems.poisson3d(24), dict(replicate_rows=1000, coarsening=1)),          # Beck: general P / R in the image
+                    (lambda: problems.random_spd(20000, 9, seed=11), dict(replicate_rows=1500, dense_limit=512, coarse_limit=40000, max_levels=3))):
+        rp, ci, v = gen()
+        n = len(rp) - 1
+        b = np.random.default_rng(3).standard_normal(n)
+        G = 3
+        res = {}
+        for share in (True, False):
+            group = sa.comm_group_create(G)
+            out = [None] * G
+            errs = []
+
+            def work(r):
+                try:
+                    A = sa.sp_matrix_mg(rp, ci, v)
+                    A.comm_init_group(group, r)
+                    A.set_setup_broadcast(share)
+                    A.setup(sa.default_params(**QUIET, **kw))
+                    lo, hi, _ = A.local_range(0)
+                    x = np.zeros(hi - lo)
+                    h, rc = A.solve("pcg", b[lo:hi].copy(), x)
+                    out[r] = (lo, x, h, rc, A.setup_share_info(), [A.level_info(l)["nrow"] for l in range(A.nlevels)], A.coarse_info())
+                    A.close()
+                except Exception as e:  # noqa: BLE001
+                    errs.append((r, repr(e)))
+
+            ts = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join(timeout=300)
+            assert not any(t.is_alive() for t in ts), "a virtual rank hung"
+            assert not errs, errs
+            sa.comm_group_destroy(group)
+            res[share] = out
+        for r in range(G):
+            built, nbytes = res[True][r][4]
+            assert built == (r == 0) and nbytes > 0
+            assert res[False][r][4] == (True, 0)
+            assert res[True][r][5] == res[False][r][5] and res[True][r][6] == res[False][r][6]
+            assert np.array_equal(res[True][r][2], res[False][r][2]) and res[True][r][3] == res[False][r][3]
+            assert np.array_equal(res[True][r][1], res[False][r][1])
+
+
 def test_fixed_cycles_bitwise_rows():
     """With reductions out of the picture (fixed number of V-cycles) the partitioned cycle is
     the same arithmetic row by row: the solution matches the single-rank one bitwise."""

@@ -115,6 +115,21 @@ def test_extended_hierarchy():
     assert A.level_info(A.nlevels - 1)["nrow"] <= 5000
 
 
+def test_hierarchy_image_roundtrip():
+    """The byte image rank 0 broadcasts in a multi-GPU setup reproduces the hierarchy array by array (HEM: aggregation
+    P; Beck: general P / R; dense coarse inverse or none), and a truncated image is refused, not half-read."""
+    for gen, kw in ((lambda: problems.poisson3d(20), {}), (lambda: problems.poisson2d(60), dict(coarsening=1)),
+                    (lambda: problems.random_spd(6000, 9, seed=3), dict(max_levels=2, dense_limit=256, coarse_limit=100000))):
+        rp, ci, v = gen()
+        A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, print_solve=0, **kw), host_only=True)
+        nbytes = A.hierarchy_roundtrip()
+        assert nbytes > 12 * (A.level_info(1)["nnz"] if A.nlevels > 1 else 0)
+        for cut in (0, 8, nbytes // 2, nbytes - 1):
+            with pytest.raises(sa.SparshError):
+                A.hierarchy_roundtrip(cut)
+        A.close()
+
+
 def test_abi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "sparsh_amg.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
