@@ -192,6 +192,16 @@ int sparsh_coarse_inverse(sparsh_handle h, double *inv);
  * number of blocks, RCM bandwidth, hierarchy extended past max_levels (1/0)}; *bytes = HBM held by the
  * factors.  After sparsh_setup (block fields are 0 for the dense form or before the device setup). */
 int sparsh_coarse_info(sparsh_handle h, int *info6, long *bytes);
+/* Interface form of the block-tridiagonal solve: where the RCM band is narrow against the block (2 * window <= block,
+ * window = bandwidth rounded up to 64) only the first / last `window` rows of a block couple to its neighbours, so the
+ * chain of dependent steps runs on those rows alone (products S_i^-1 A[i,neighbour] kept in HBM) and everything else is
+ * two whole-level launches; the chain itself -- an affine recurrence with constant W x W matrices -- is unrolled at setup
+ * into block-triangular matrices, so each of its two passes is ONE triangular matrix-vector product (while those matrices
+ * stay under 1 GiB; otherwise one launch per chain step).  *window = 0 when the solver does not use the form.
+ * sparsh_set_coarse_interface(h, mode) before sparsh_setup: 0 keeps the plain chain of B x B steps, 1 (default) as
+ * described, 2 the interface form with one launch per chain step (A/B measurements). */
+int sparsh_coarse_window(sparsh_handle h, int *window);
+int sparsh_set_coarse_interface(sparsh_handle h, int enable);
 double sparsh_setup_seconds(sparsh_handle h);
 
 /* AMG_solver::AMG_solve_jacobi(b, x, iterations) (src/AMG_phases.cpp:151-230) ==

@@ -101,6 +101,8 @@ def _load():
         "sparsh_coarse_inverse": (C.c_int, [H, c_dbl_p]),
         "sparsh_op_precond_f32": (C.c_int, [H, c_dbl_p, c_dbl_p]),
         "sparsh_coarse_info": (C.c_int, [H, c_int_p, C.POINTER(C.c_long)]),
+        "sparsh_coarse_window": (C.c_int, [H, c_int_p]),
+        "sparsh_set_coarse_interface": (C.c_int, [H, C.c_int]),
         "sparsh_setup_seconds": (C.c_double, [H]),
         "sparsh_vcycle": (C.c_int, [H, c_dbl_p, c_dbl_p, C.c_int, c_dbl_p, C.c_int, c_int_p]),
         "sparsh_vcycle_dev": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int, c_dbl_p, C.c_int, c_int_p]),
@@ -378,8 +380,15 @@ class sp_matrix_mg:
         info = (C.c_int * 6)()
         nbytes = C.c_long(0)
         _check(lib.sparsh_coarse_info(self._h, info, C.byref(nbytes)))
+        win = C.c_int(0)
+        _check(lib.sparsh_coarse_window(self._h, C.byref(win)))
         return {"rows": info[0], "dense": bool(info[1]), "block": info[2], "nblocks": info[3], "bandwidth": info[4],
-                "extended": bool(info[5]), "bytes": nbytes.value}
+                "extended": bool(info[5]), "bytes": nbytes.value, "window": win.value}
+
+    def set_coarse_interface(self, enable=True):
+        """Interface (window) form of the block-tridiagonal coarse solve, default on; call before setup."""
+        _check(lib.sparsh_set_coarse_interface(self._h, int(enable)))
+        return self
 
     def set_deep_halo(self, enable=True):
         """Deep-halo smoothing on partitioned levels (default on; call before setup)."""

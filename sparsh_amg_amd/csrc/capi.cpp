@@ -419,6 +419,22 @@ int sparsh_coarse_info(sparsh_handle h, int *info6, long *bytes)
     return SPARSH_OK;
 }
 
+int sparsh_set_coarse_interface(sparsh_handle h, int enable)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    h->eng->coarse_mut().set_allow_windowed(enable != 0);
+    h->eng->coarse_mut().set_unrolled_chain(enable != 2);
+    return SPARSH_OK;
+}
+
+int sparsh_coarse_window(sparsh_handle h, int *window)
+{
+    REQUIRE_HOST(h);
+    const CoarseSolver &c = h->eng->coarse();
+    if (window) *window = (c.ready() && !c.dense() && c.windowed()) ? c.window() : 0;
+    return SPARSH_OK;
+}
+
 double sparsh_setup_seconds(sparsh_handle h) { return (h && h->eng) ? h->eng->setup_seconds : 0.0; }
 
 int sparsh_vcycle(sparsh_handle h, const double *b, double *x, int iterations, double *hist, int hist_cap, int *ncycles)

@@ -88,6 +88,17 @@ void CoarseSolver::release()
     for (void *p : allocs_) (void)hipFree(p);
     allocs_.clear();
     inv_ = sinv_ = z_ = nullptr;
+    g_ = h_ = y_ = xw_ = nullptr;
+    wdesc_ = nullptr;
+    for (int c = 0; c < 2; ++c) {
+        L_[c] = U_[c] = nullptr;
+        in_idx_[c] = out_idx_[c] = nullptr;
+        chain_m_[c] = 0;
+    }
+    unrolled_ = false;
+    tri_bytes_ = 0;
+    windowed_ = false;
+    win_ = 0;
     perm_ = nullptr;
     out_ = in_ = BtDevCsr();
     out_ell_ = in_ell_ = BtDevEll();
@@ -165,6 +176,10 @@ bool CoarseSolver::setup_dense(int n, const double *inv_host, std::string &err)
     return true;
 }
 
+namespace {
+int up64w(int x) { return (x + 63) / 64 * 64; }
+}  // namespace
+
 bool CoarseSolver::setup_bt(const HostCsr &A, hipStream_t st, std::string &err, int *why_failed)
 {
     release();
@@ -215,6 +230,124 @@ bool CoarseSolver::setup_bt(const HostCsr &A, hipStream_t st, std::string &err, 
     for (int i = 0; i < mid; ++i) factor_block(i, i - 1, -1);          // top chain
     for (int i = nb - 1; i > mid; --i) factor_block(i, i + 1, -1);     // bottom chain
     factor_block(mid, mid - 1, mid + 1);                                // middle block
+    // interface form of the solve where the band is narrow against the block (see coarse_kernels.hip): the products
+    // G_i = S_i^-1 A[i,outer], H_i = S_i^-1 A[i,inner] on the neighbour's window columns, and the window of every block
+    const int W = up64w(std::max(P.bw, 1));
+    if (allow_windowed_ && 2 * W <= B && nb >= 3) {
+        HostCsr outT = transpose(P.out);
+        BtDevCsr outT_d;
+        std::vector<int> wd((size_t)4 * nb, 0);
+        auto top_win = [&](int j, int &w0, int &wn) {
+            wn = std::min(W, P.block_rows(j));
+            w0 = j * B;
+        };
+        auto bot_win = [&](int j, int &w0, int &wn) {
+            wn = std::min(W, P.block_rows(j));
+            w0 = j * B + P.block_rows(j) - wn;
+        };
+        for (int i = 0; i < nb; ++i) {
+            int *d = &wd[(size_t)4 * i];
+            if (i < mid) {
+                if (i >= 1) bot_win(i - 1, d[0], d[1]);
+                top_win(i + 1, d[2], d[3]);
+            } else if (i > mid) {
+                if (i + 1 < nb) top_win(i + 1, d[0], d[1]);
+                bot_win(i - 1, d[2], d[3]);
+            } else {
+                if (mid >= 1) bot_win(mid - 1, d[0], d[1]);
+                if (mid + 1 < nb) top_win(mid + 1, d[2], d[3]);
+            }
+        }
+        bool okw = upload_piece(tmp, outT, outT_d, err);
+        g_ = okw ? dev_alloc<double>(allocs_, (size_t)nb * B * W, err) : nullptr;
+        h_ = okw ? dev_alloc<double>(allocs_, (size_t)nb * B * W, err) : nullptr;
+        y_ = okw ? dev_alloc<double>(allocs_, (size_t)n, err) : nullptr;
+        xw_ = okw ? dev_alloc<double>(allocs_, (size_t)n, err) : nullptr;
+        wdesc_ = okw ? dev_upload(allocs_, wd.data(), wd.size(), err) : nullptr;
+        if (!(okw && g_ && h_ && y_ && xw_ && wdesc_)) {
+            drop_tmp();
+            release();
+            return false;
+        }
+        (void)hipMemsetAsync(g_, 0, (size_t)nb * B * W * sizeof(double), st);
+        (void)hipMemsetAsync(h_, 0, (size_t)nb * B * W * sizeof(double), st);
+        (void)hipMemsetAsync(y_, 0, (size_t)n * sizeof(double), st);
+        (void)hipMemsetAsync(xw_, 0, (size_t)n * sizeof(double), st);
+        for (int i = 0; i < nb; ++i) {
+            const int *d = &wd[(size_t)4 * i];
+            const double *Si = sinv_ + (size_t)i * bstride;
+            if (d[1] > 0) bt_launch_winprod(i * B, P.block_rows(i), B, Si, outT_d, d[0], d[1], W, g_ + (size_t)i * B * W, st);
+            if (d[3] > 0) bt_launch_winprod(i * B, P.block_rows(i), B, Si, i == mid ? outT_d : inT, d[2], d[3], W, h_ + (size_t)i * B * W, st);
+        }
+        windowed_ = true;
+        win_ = W;
+        // the two chains unrolled into block-triangular matrices (coarse_kernels.hip): chain position k = 0 is the block at
+        // the chain's end, k = m - 1 the block next to the middle one
+        const int mc[2] = {mid, nb - 1 - mid};
+        size_t tri = 0;
+        for (int c = 0; c < 2; ++c) tri += ((size_t)mc[c] * W * mc[c] * W + (size_t)(mc[c] + 1) * W * (mc[c] + 1) * W) * sizeof(double);
+        if (unroll_chain_ && tri <= ((size_t)1 << 30)) {
+            bool okt = true;
+            for (int c = 0; c < 2 && okt; ++c) {
+                const int m = mc[c];
+                chain_m_[c] = m;
+                auto blk_of = [&](int k) { return c == 0 ? k : nb - 1 - k; };
+                // inward-facing window: top chain = last rows, bottom chain = first rows; outward-facing the other one
+                auto win_rows = [&](int blk, bool inward, int &first, int &nt) {
+                    const int bs = P.block_rows(blk);
+                    nt = std::min(W, bs);
+                    const bool bottom = inward == (c == 0);
+                    first = blk * B + (bottom ? bs - nt : 0);
+                };
+                std::vector<int> iin((size_t)m * W, -1), iout((size_t)(m + 1) * W, -1);
+                for (int k = 0; k < m; ++k) {
+                    int f, nt;
+                    win_rows(blk_of(k), true, f, nt);
+                    for (int q = 0; q < nt; ++q) iin[(size_t)k * W + q] = f + q;
+                    win_rows(blk_of(k), false, f, nt);
+                    for (int q = 0; q < nt; ++q) iout[(size_t)k * W + q] = f + q;
+                }
+                {   // the middle block's window that faces this chain
+                    const int bs = P.block_rows(mid), nt = std::min(W, bs);
+                    const int f = mid * B + (c == 0 ? 0 : bs - nt);
+                    for (int q = 0; q < nt; ++q) iout[(size_t)m * W + q] = f + q;
+                }
+                const int ldl = m * W, ldu = (m + 1) * W;
+                L_[c] = dev_alloc<double>(allocs_, (size_t)std::max(ldl, 1) * std::max(ldl, 1), err);
+                U_[c] = dev_alloc<double>(allocs_, (size_t)ldu * ldu, err);
+                in_idx_[c] = dev_upload(allocs_, iin.data(), iin.size(), err);
+                out_idx_[c] = dev_upload(allocs_, iout.data(), iout.size(), err);
+                okt = L_[c] && U_[c] && in_idx_[c] && out_idx_[c];
+                if (!okt) break;
+                (void)hipMemsetAsync(L_[c], 0, (size_t)std::max(ldl, 1) * std::max(ldl, 1) * sizeof(double), st);
+                (void)hipMemsetAsync(U_[c], 0, (size_t)ldu * ldu * sizeof(double), st);
+                for (int k = 0; k < m; ++k) {  // L[k][k] = I ; L[k][0 .. k) = -C_k L[k-1][0 .. k)
+                    int f, nt;
+                    win_rows(blk_of(k), true, f, nt);
+                    double *Lk = L_[c] + (size_t)k * W * ldl;
+                    bt_launch_identity(Lk + (size_t)k * W, ldl, nt, st);
+                    if (k >= 1) bt_launch_chain_mul(g_ + (size_t)f * W, nt, W, L_[c] + (size_t)(k - 1) * W * ldl, ldl, k * W, Lk, ldl, st);
+                }
+                // U[m][m] = I (the middle block's window) ; U[k][k] = I ; U[k][(k+1) .. m] = -D_k U[k+1][(k+1) .. m]
+                bt_launch_identity(U_[c] + (size_t)m * W * ldu + (size_t)m * W, ldu, W, st);
+                for (int k = m - 1; k >= 0; --k) {
+                    int f, nt;
+                    win_rows(blk_of(k), false, f, nt);
+                    double *Uk = U_[c] + (size_t)k * W * ldu;
+                    bt_launch_identity(Uk + (size_t)k * W, ldu, nt, st);
+                    bt_launch_chain_mul(h_ + (size_t)f * W, nt, W, U_[c] + (size_t)(k + 1) * W * ldu + (size_t)(k + 1) * W, ldu, (m - k) * W,
+                                        Uk + (size_t)(k + 1) * W, ldu, st);
+                }
+            }
+            if (!okt) {
+                drop_tmp();
+                release();
+                return false;
+            }
+            unrolled_ = true;
+            tri_bytes_ = tri;
+        }
+    }
     int sing_h = 0;
     const bool copied = hipMemcpyAsync(&sing_h, sing, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess;
     const hipError_t e = hipStreamSynchronize(st);
@@ -277,6 +410,22 @@ void CoarseSolver::solve(const double *b, double *x, hipStream_t st) const
         return;
     }
     const size_t bstride = (size_t)plan_.B * plan_.B;
+    if (windowed_) {
+        const int B = plan_.B, nb = plan_.nb;
+        bt_launch_prepass(nb, B, n_, bstride, sinv_, perm_, b, y_, st);
+        if (unrolled_) {
+            const int ldl[2] = {chain_m_[0] * win_, chain_m_[1] * win_}, ldu[2] = {(chain_m_[0] + 1) * win_, (chain_m_[1] + 1) * win_};
+            bt_launch_tri_gemv(L_, in_idx_, ldl, ldl, win_, 1, y_, z_, st);           // z on the inward-facing windows
+            bt_launch_win_mid(nb, B, n_, win_, plan_.mid, wdesc_, g_, h_, y_, z_, xw_, st);  // z on the outward-facing ones, middle block
+            bt_launch_tri_gemv(U_, out_idx_, ldu, ldl, win_, 0, z_, xw_, st);         // x on the outward-facing windows
+            bt_launch_win_final(nb, B, n_, win_, plan_.mid, wdesc_, g_, h_, y_, z_, xw_, perm_, x, st);
+            return;
+        }
+        for (const Step &s : steps_)
+            bt_launch_win_step(s.blk, s.nblk, s.mode == 1 ? 1 : (s.final_ ? 2 : 0), B, n_, win_, wdesc_, g_, h_, y_, z_, xw_, st);
+        bt_launch_win_final(nb, B, n_, win_, plan_.mid, wdesc_, g_, h_, y_, z_, xw_, perm_, x, st);
+        return;
+    }
     for (const Step &s : steps_)
         bt_launch_solve_step(s.r0, s.bs, s.blk, s.nblk, s.mode, s.final_, plan_.B, bstride, sinv_, perm_, s.mode == 0 ? out_ : in_,
                              s.mode == 0 ? out_ell_ : in_ell_, n_, b, z_, x, st);

@@ -70,11 +70,17 @@ public:
     int block() const { return plan_.B; }
     int nblocks() const { return plan_.nb; }
     int bandwidth() const { return plan_.bw; }
+    bool windowed() const { return windowed_; }
+    int window() const { return win_; }
+    void set_allow_windowed(bool on) { allow_windowed_ = on; }  // before setup_bt (A/B measurements)
+    void set_unrolled_chain(bool on) { unroll_chain_ = on; }  // interface form: chain passes as triangular products (default) or step by step
+    bool unrolled() const { return unrolled_; }
     const double *dense_inverse() const { return inv_; }
-    size_t bytes() const { return dense_ ? (size_t)n_ * n_ * 8 : plan_.sinv_bytes(); }
+    size_t bytes() const { return dense_ ? (size_t)n_ * n_ * 8 : plan_.sinv_bytes() + (windowed_ ? (size_t)2 * plan_.nb * plan_.B * win_ * 8 : 0) + tri_bytes_; }
     double factor_seconds = 0.0;
 
 private:
+    bool allow_windowed_ = true, unroll_chain_ = true;
     int n_ = 0;
     bool dense_ = true;
     double *inv_ = nullptr;  // dense form
@@ -83,6 +89,20 @@ private:
     int *perm_ = nullptr;
     BtDevCsr out_, in_;
     BtDevEll out_ell_, in_ell_;
+    // interface ("window") form of the solve for narrow bands (2 * window <= block): only the first / last `win_` rows
+    // of a block couple to its neighbours, so the dependent chain runs on those rows alone, with the products
+    // G_i = S_i^-1 A[i,outer] and H_i = S_i^-1 A[i,inner] (restricted to the neighbour's window columns) kept in HBM
+    bool windowed_ = false;
+    int win_ = 0;                      // window width W (multiple of 64)
+    double *g_ = nullptr, *h_ = nullptr;  // nb x B x W each (row-major per block, leading dimension W)
+    double *y_ = nullptr, *xw_ = nullptr;
+    int *wdesc_ = nullptr;             // per block: {gwin0, gwn, hwin0, hwn}
+    // the two chains (0 top, 1 bottom) unrolled: L_ (m W x m W) and U_ ((m + 1) W x (m + 1) W) per chain, position -> row index maps
+    bool unrolled_ = false;
+    double *L_[2] = {nullptr, nullptr}, *U_[2] = {nullptr, nullptr};
+    int *in_idx_[2] = {nullptr, nullptr}, *out_idx_[2] = {nullptr, nullptr};
+    int chain_m_[2] = {0, 0};
+    size_t tri_bytes_ = 0;
     std::vector<void *> allocs_;
     struct Step {
         int r0[2], bs[2], blk[2], nblk, mode, final_;
@@ -99,6 +119,25 @@ void bt_launch_invert(int bs, int ld, double *S, double *S2, double *col0, doubl
 void bt_launch_solve_step(const int r0[2], const int bs[2], const int blk[2], int nblk, int mode, int final_, int ld, size_t blk_stride,
                           const double *sinv, const int *perm, const BtDevCsr &A, const BtDevEll &E, int n, const double *b, double *z, double *x,
                           hipStream_t st);
+// G or H of one block: out[r][c] = sum_k Sinv[r][k] X[r0+k][win0+c], XT = CSR of the transposed coupling piece
+void bt_launch_winprod(int r0, int bs, int ld, const double *Sinv, const BtDevCsr &XT, int win0, int wn, int ldw, double *out, hipStream_t st);
+// interface-form solve: pre-pass y = blockdiag(S^-1) b[perm] over all blocks
+void bt_launch_prepass(int nb, int B, int n, size_t blk_stride, const double *sinv, const int *perm, const double *b, double *y, hipStream_t st);
+// one chain step on the window rows of up to two blocks; mode 0 inward (zw = y - G zw[gwin]), 2 middle block
+// (zw = xw = y - G zw[gwin] - H zw[hwin]), 1 outward (xw = zw - H xw[hwin])
+void bt_launch_win_step(const int blk[2], int nblk, int mode, int B, int n, int W, const int *wdesc, const double *g, const double *h,
+                        const double *y, double *zw, double *xw, hipStream_t st);
+// chain unrolled at setup: Out = -C X (W x K), identity on a diagonal block, and the triangular matrix-vector product of a pass
+void bt_launch_chain_mul(const double *C, int nt, int W, const double *X, int ldx, int K, double *Out, int ldo, hipStream_t st);
+void bt_launch_identity(double *M, int ld, int nt, hipStream_t st);
+void bt_launch_tri_gemv(const double *const M[2], const int *const idx[2], const int ld[2], const int rows[2], int W, int lower,
+                        const double *src, double *dst, hipStream_t st);
+// z at the outward-facing windows of all chain blocks + the middle block (between the two chain passes)
+void bt_launch_win_mid(int nb, int B, int n, int W, int mid, const int *wdesc, const double *g, const double *h, const double *y, double *zw,
+                       double *xw, hipStream_t st);
+// all rows: x[perm[r]] = y[r] - G zw[gwin] - H (mid ? zw : xw)[hwin]
+void bt_launch_win_final(int nb, int B, int n, int W, int mid, const int *wdesc, const double *g, const double *h, const double *y,
+                         const double *zw, const double *xw, const int *perm, double *x, hipStream_t st);
 void launch_cvt_f2d(int n, const float *in, double *out, hipStream_t st);
 
 }  // namespace sparsh

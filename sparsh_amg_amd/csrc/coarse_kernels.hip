@@ -300,6 +300,259 @@ __global__ __launch_bounds__(kCB) void bt_solve_kernel(BtStep s, int mode, int f
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Interface ("window") form of the solve for narrow bands.  With block size B >= 2 W (W = bandwidth rounded up
+// to 64) only the first / last W rows of a block have entries in a neighbour block, so with
+//     G_i = S_i^-1 A[i,outer]   H_i = S_i^-1 A[i,inner]        (columns restricted to the neighbour's window)
+// the recurrences of the solve read
+//     y   = blockdiag(S^-1) b                                       one launch over all blocks, no dependency
+//     z_i = y_i - G_i z_outer[window]                               inward, needed on the window rows only
+//     x_i = z_i - H_i x_inner[window]                               outward, window rows only
+//     x_i = y_i - G_i z_outer[window] - H_i x_inner[window]         one launch over all rows at the end
+// The dependent chain then moves 2W x W numbers per block instead of B x B.
+// G / H of one block: one workgroup per row r of the block, one thread per window column c:
+//     out[r][c] = sum over the entries (k, v) of column win0 + c of the coupling piece with k in the block: Sinv[r][k - r0] * v
+// (XT = CSR of the transposed piece, so a column's entries come in a fixed order: deterministic).
+__global__ __launch_bounds__(kCB) void bt_winprod_kernel(int r0, int bs, int ld, const double *__restrict__ Sinv, const int *__restrict__ t_rp,
+                                                         const int *__restrict__ t_ci, const double *__restrict__ t_v, int win0, int wn, int ldw,
+                                                         double *__restrict__ out)
+{
+    const int r = blockIdx.x;
+    const double *__restrict__ srow = Sinv + (size_t)r * ld;
+    double *__restrict__ orow = out + (size_t)r * ldw;
+    for (int c = threadIdx.x; c < ldw; c += kCB) {
+        double acc = 0.0;
+        if (c < wn) {
+            const int gc = win0 + c;
+            for (int j = t_rp[gc]; j < t_rp[gc + 1]; ++j) {
+                const int k = t_ci[j];
+                if (k >= r0 && k < r0 + bs) acc += srow[k - r0] * t_v[j];
+            }
+        }
+        orow[c] = acc;
+    }
+}
+
+// y = blockdiag(S^-1) b[perm]: blockIdx.y = block, each workgroup kSolveRows rows (a wave takes two), b of the block in LDS
+__global__ __launch_bounds__(kCB) void bt_prepass_kernel(int B, int n, size_t blk_stride, const double *__restrict__ sinv,
+                                                         const int *__restrict__ perm, const double *__restrict__ b, double *__restrict__ y)
+{
+    extern __shared__ double w[];
+    const int blk = blockIdx.y;
+    const int r0 = blk * B;
+    const int bs = min(B, n - r0);
+    const int row0 = blockIdx.x * kSolveRows;
+    if (row0 >= bs) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const double *__restrict__ M = sinv + (size_t)blk * blk_stride;
+    const int ra = row0 + 2 * wv, rb = ra + 1;
+    const bool ha = ra < bs, hb = rb < bs;
+    const double *__restrict__ ma = M + (size_t)(ha ? ra : 0) * B;
+    const double *__restrict__ mb = M + (size_t)(hb ? rb : (ha ? ra : 0)) * B;
+    constexpr int U = 8;
+    double2 va[U], vb[U];
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = c0 + lane * 2 + u * 128;
+            const bool ok = j < bs;
+            va[u] = ok ? *reinterpret_cast<const double2 *>(ma + j) : double2{0.0, 0.0};
+            vb[u] = ok ? *reinterpret_cast<const double2 *>(mb + j) : double2{0.0, 0.0};
+        }
+    };
+    load_chunk(0);
+    for (int r = threadIdx.x; r < bs; r += kCB) w[r] = b[perm[r0 + r]];
+    __syncthreads();
+    double sa = 0.0, sb = 0.0;
+    for (int c0 = 0; c0 < bs; c0 += U * 128) {
+        if (c0 > 0) load_chunk(c0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = c0 + lane * 2 + u * 128;
+            const double w0 = j < bs ? w[j] : 0.0, w1 = j + 1 < bs ? w[j + 1] : 0.0;
+            sa += va[u].x * w0;
+            sa += va[u].y * w1;
+            sb += vb[u].x * w0;
+            sb += vb[u].y * w1;
+        }
+    }
+    sa = wsum(sa);
+    sb = wsum(sb);
+    if (lane == 0 && ha) {
+        y[r0 + ra] = sa;
+        if (hb) y[r0 + rb] = sb;
+    }
+}
+
+// dot of one row of G / H (W doubles, W a multiple of 64) with the window vector v[0 .. wn): whole wave, result in all lanes of lane 0's reduction
+__device__ __forceinline__ double win_dot(const double *__restrict__ row, const double *__restrict__ v, int wn, int W, int lane)
+{
+    double acc = 0.0;
+    for (int c = lane; c < W; c += 64) {
+        const double m = row[c];
+        const double t = c < wn ? v[c] : 0.0;
+        acc += m != 0.0 ? m * t : 0.0;  // zero padding / structural zeros must not pick up a NaN a broken-down solve left behind
+    }
+    return wsum(acc);
+}
+
+struct BtWinStep {
+    int blk[2];
+    int nblk;
+};
+
+// window rows of a block: the first and the last nt = min(W, bs) rows (all rows when they overlap)
+__device__ __forceinline__ int win_row(int q, int bs, int nt)
+{
+    if (2 * nt >= bs) return q;
+    return q < nt ? q : bs - 2 * nt + q;
+}
+
+// one chain step (see bt_launch_win_step); one wave per window row
+__global__ __launch_bounds__(kCB) void bt_win_step_kernel(BtWinStep s, int mode, int B, int n, int W, const int *__restrict__ wdesc,
+                                                          const double *__restrict__ g, const double *__restrict__ h,
+                                                          const double *__restrict__ y, double *__restrict__ zw, double *__restrict__ xw)
+{
+    const int blk = s.blk[blockIdx.y];
+    const int r0 = blk * B;
+    const int bs = min(B, n - r0);
+    const int nt = min(W, bs);
+    const int nq = 2 * nt >= bs ? bs : 2 * nt;
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * (kCB / 64) + (threadIdx.x >> 6);
+    if (q >= nq) return;  // wave-uniform
+    const int lr = win_row(q, bs, nt);
+    const int gwin0 = wdesc[4 * blk], gwn = wdesc[4 * blk + 1], hwin0 = wdesc[4 * blk + 2], hwn = wdesc[4 * blk + 3];
+    const size_t ro = ((size_t)blk * B + lr) * W;
+    const int gr = r0 + lr;
+    double val;
+    if (mode == 1) {
+        val = zw[gr];
+        if (hwn > 0) val -= win_dot(h + ro, xw + hwin0, hwn, W, lane);
+    } else {
+        val = y[gr];
+        if (gwn > 0) val -= win_dot(g + ro, zw + gwin0, gwn, W, lane);
+        if (mode == 2 && hwn > 0) val -= win_dot(h + ro, zw + hwin0, hwn, W, lane);
+    }
+    if (lane == 0) {
+        if (mode == 1) {
+            xw[gr] = val;
+        } else {
+            zw[gr] = val;
+            if (mode == 2) xw[gr] = val;
+        }
+    }
+}
+
+// ---- the window chain unrolled at setup -------------------------------------------------------------------
+// The inward recurrence on the inward-facing windows, zw_k = yw_k - C_k zw_{k-1} (k = chain position, C_k = the window
+// rows of G of that block, W x W), is an affine recurrence with constant matrices: unrolled once at setup it reads
+// zw = L yw with L block lower triangular, L[k][k] = I, L[k][j] = -C_k L[k-1][j].  Likewise the outward recurrence on the
+// outward-facing windows, xo_k = zo_k - D_k xo_{k+1}: xo = U [zo; x_mid] with U block upper triangular.  A chain pass is
+// then ONE whole-chip launch (a triangular matrix-vector product of (m W)^2 / 2 numbers) instead of m dependent steps.
+// Out[q][c] = - sum_t C[q][t] X[t][c]   (q < nt rows of C are valid, the rest of Out stays zero); grid (ceil(K / 256), W)
+__global__ __launch_bounds__(kCB) void bt_chain_mul_kernel(const double *__restrict__ C, int nt, int W, const double *__restrict__ X, int ldx,
+                                                           int K, double *__restrict__ Out, int ldo)
+{
+    const int q = blockIdx.y;
+    const int c = blockIdx.x * kCB + threadIdx.x;
+    if (c >= K) return;
+    double acc = 0.0;
+    if (q < nt) {
+        const double *__restrict__ crow = C + (size_t)q * W;
+        for (int t = 0; t < W; ++t) acc += crow[t] * X[(size_t)t * ldx + c];
+    }
+    Out[(size_t)q * ldo + c] = -acc;
+}
+
+__global__ __launch_bounds__(kCB) void bt_identity_kernel(double *__restrict__ M, int ld, int nt)
+{
+    const int i = blockIdx.x * kCB + threadIdx.x;
+    if (i < nt) M[(size_t)i * ld + i] = 1.0;
+}
+
+struct BtTri {
+    const double *M[2];   // per chain: (rows x ld) row-major
+    const int *idx[2];    // per chain: position -> index into src / dst (-1: padding)
+    int ld[2], rows[2];   // rows to compute (m_c * W)
+};
+
+// dst[idx[r]] = sum_c M[r][c] src[idx[c]] over the columns of the triangle: lower: c < (r / W + 1) W; upper: (r / W) W <= c < ld.
+// blockIdx.y = chain; one wave per row.
+__global__ __launch_bounds__(kCB) void bt_tri_gemv_kernel(BtTri t, int W, int lower, const double *__restrict__ src, double *__restrict__ dst)
+{
+    const int c = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (kCB / 64) + (threadIdx.x >> 6);
+    if (r >= t.rows[c]) return;
+    const int *__restrict__ idx = t.idx[c];
+    const int out = idx[r];
+    if (out < 0) return;  // padding row of a short block
+    const int ld = t.ld[c];
+    const double *__restrict__ row = t.M[c] + (size_t)r * ld;
+    const int k = r / W;
+    const int c0 = lower ? 0 : k * W, c1 = lower ? (k + 1) * W : ld;
+    double acc = 0.0;
+    for (int j = c0 + lane; j < c1; j += 64) {
+        const double m = row[j];
+        const int ix = idx[j];
+        const double v = ix >= 0 ? src[ix] : 0.0;
+        acc += m != 0.0 ? m * v : 0.0;
+    }
+    acc = wsum(acc);
+    if (lane == 0) dst[out] = acc;
+}
+
+// between the two chain launches: z at the outward-facing window of every chain block (needs only what the inward chain left),
+// and the middle block: z = x = y - G z[gwin] - H z[hwin] at both its windows.  blockIdx.y = block, one wave per row.
+__global__ __launch_bounds__(kCB) void bt_win_mid_kernel(int B, int n, int W, int mid, const int *__restrict__ wdesc, const double *__restrict__ g,
+                                                         const double *__restrict__ h, const double *__restrict__ y, double *__restrict__ zw,
+                                                         double *__restrict__ xw)
+{
+    const int blk = blockIdx.y;
+    const int r0 = blk * B;
+    const int bs = min(B, n - r0);
+    const int nt = min(W, bs);
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * (kCB / 64) + (threadIdx.x >> 6);
+    int lr;
+    if (blk == mid) {
+        const int nq = 2 * nt >= bs ? bs : 2 * nt;
+        if (q >= nq) return;
+        lr = win_row(q, bs, nt);
+    } else {
+        if (q >= nt) return;
+        lr = blk < mid ? q : bs - nt + q;  // top chain: first rows face outward; bottom chain: last rows
+    }
+    const int gwin0 = wdesc[4 * blk], gwn = wdesc[4 * blk + 1], hwin0 = wdesc[4 * blk + 2], hwn = wdesc[4 * blk + 3];
+    const size_t ro = ((size_t)r0 + lr) * W;
+    const int gr = r0 + lr;
+    double val = y[gr];
+    if (gwn > 0) val -= win_dot(g + ro, zw + gwin0, gwn, W, lane);
+    if (blk == mid && hwn > 0) val -= win_dot(h + ro, zw + hwin0, hwn, W, lane);
+    if (lane == 0) {
+        zw[gr] = val;
+        if (blk == mid) xw[gr] = val;
+    }
+}
+
+// all rows of all blocks: x[perm[r]] = y[r] - G zw[gwin] - H (block == mid ? zw : xw)[hwin]; one wave per row
+__global__ __launch_bounds__(kCB) void bt_win_final_kernel(int B, int n, int W, int mid, const int *__restrict__ wdesc, const double *__restrict__ g,
+                                                           const double *__restrict__ h, const double *__restrict__ y, const double *__restrict__ zw,
+                                                           const double *__restrict__ xw, const int *__restrict__ perm, double *__restrict__ x)
+{
+    const int lane = threadIdx.x & 63;
+    const int gr = blockIdx.x * (kCB / 64) + (threadIdx.x >> 6);
+    if (gr >= n) return;
+    const int blk = gr / B;
+    const int gwin0 = wdesc[4 * blk], gwn = wdesc[4 * blk + 1], hwin0 = wdesc[4 * blk + 2], hwn = wdesc[4 * blk + 3];
+    const size_t ro = (size_t)gr * W;  // = (blk * B + local row) * W
+    double val = y[gr];
+    if (gwn > 0) val -= win_dot(g + ro, zw + gwin0, gwn, W, lane);
+    if (hwn > 0) val -= win_dot(h + ro, (blk == mid ? zw : xw) + hwin0, hwn, W, lane);
+    if (lane == 0) x[perm[gr]] = val;
+}
+
 __global__ __launch_bounds__(kCB) void cvt_f2d_kernel(int n, const float *__restrict__ in, double *__restrict__ out)
 {
     for (int i = blockIdx.x * kCB + threadIdx.x; i < n; i += gridDim.x * kCB) out[i] = (double)in[i];
@@ -355,6 +608,70 @@ void bt_launch_solve_step(const int r0[2], const int bs[2], const int blk[2], in
     const int gx = (mx + kSolveRows - 1) / kSolveRows;
     hipLaunchKernelGGL(bt_solve_kernel, dim3(gx, nblk), dim3(kCB), (size_t)mx * sizeof(double), st, s, mode, final_, ld, blk_stride, sinv, perm,
                        A.rp, A.ci, A.v, E.k, n, E.ci, E.v, b, z, x);
+}
+
+void bt_launch_winprod(int r0, int bs, int ld, const double *Sinv, const BtDevCsr &XT, int win0, int wn, int ldw, double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(bt_winprod_kernel, dim3(bs), dim3(kCB), 0, st, r0, bs, ld, Sinv, XT.rp, XT.ci, XT.v, win0, wn, ldw, out);
+}
+
+void bt_launch_prepass(int nb, int B, int n, size_t blk_stride, const double *sinv, const int *perm, const double *b, double *y, hipStream_t st)
+{
+    hipLaunchKernelGGL(bt_prepass_kernel, dim3((B + kSolveRows - 1) / kSolveRows, nb), dim3(kCB), (size_t)B * sizeof(double), st, B, n, blk_stride, sinv,
+                       perm, b, y);
+}
+
+void bt_launch_win_step(const int blk[2], int nblk, int mode, int B, int n, int W, const int *wdesc, const double *g, const double *h,
+                        const double *y, double *zw, double *xw, hipStream_t st)
+{
+    BtWinStep s;
+    s.blk[0] = blk[0];
+    s.blk[1] = blk[nblk > 1 ? 1 : 0];
+    s.nblk = nblk;
+    const int rows = 2 * W < B ? 2 * W : B;  // most window rows a block can have
+    hipLaunchKernelGGL(bt_win_step_kernel, dim3((rows + kCB / 64 - 1) / (kCB / 64), nblk), dim3(kCB), 0, st, s, mode, B, n, W, wdesc, g, h, y, zw, xw);
+}
+
+void bt_launch_chain_mul(const double *C, int nt, int W, const double *X, int ldx, int K, double *Out, int ldo, hipStream_t st)
+{
+    if (K <= 0) return;
+    hipLaunchKernelGGL(bt_chain_mul_kernel, dim3((K + kCB - 1) / kCB, W), dim3(kCB), 0, st, C, nt, W, X, ldx, K, Out, ldo);
+}
+
+void bt_launch_identity(double *M, int ld, int nt, hipStream_t st)
+{
+    if (nt <= 0) return;
+    hipLaunchKernelGGL(bt_identity_kernel, dim3((nt + kCB - 1) / kCB), dim3(kCB), 0, st, M, ld, nt);
+}
+
+void bt_launch_tri_gemv(const double *const M[2], const int *const idx[2], const int ld[2], const int rows[2], int W, int lower,
+                        const double *src, double *dst, hipStream_t st)
+{
+    BtTri t;
+    int mx = 0;
+    for (int c = 0; c < 2; ++c) {
+        t.M[c] = M[c];
+        t.idx[c] = idx[c];
+        t.ld[c] = ld[c];
+        t.rows[c] = rows[c];
+        mx = rows[c] > mx ? rows[c] : mx;
+    }
+    if (mx <= 0) return;
+    hipLaunchKernelGGL(bt_tri_gemv_kernel, dim3((mx + kCB / 64 - 1) / (kCB / 64), 2), dim3(kCB), 0, st, t, W, lower, src, dst);
+}
+
+void bt_launch_win_mid(int nb, int B, int n, int W, int mid, const int *wdesc, const double *g, const double *h, const double *y, double *zw,
+                       double *xw, hipStream_t st)
+{
+    const int rows = 2 * W < B ? 2 * W : B;
+    hipLaunchKernelGGL(bt_win_mid_kernel, dim3((rows + kCB / 64 - 1) / (kCB / 64), nb), dim3(kCB), 0, st, B, n, W, mid, wdesc, g, h, y, zw, xw);
+}
+
+void bt_launch_win_final(int nb, int B, int n, int W, int mid, const int *wdesc, const double *g, const double *h, const double *y,
+                         const double *zw, const double *xw, const int *perm, double *x, hipStream_t st)
+{
+    (void)nb;
+    hipLaunchKernelGGL(bt_win_final_kernel, dim3((n + kCB / 64 - 1) / (kCB / 64)), dim3(kCB), 0, st, B, n, W, mid, wdesc, g, h, y, zw, xw, perm, x);
 }
 
 void launch_cvt_f2d(int n, const float *in, double *out, hipStream_t st)

@@ -93,6 +93,7 @@ public:
     int nlevels() const { return (int)lev_.size(); }
     const HostHierarchy &host() const { return H_; }
     const CoarseSolver &coarse() const { return coarse_; }
+    CoarseSolver &coarse_mut() { return coarse_; }
     const sparsh_params &params() const { return prm_; }
     // kernel-family / layout choices of THIS handle (const_slots is read when the layouts are built)
     KernelConfig &kernel_cfg() { return cfg_; }

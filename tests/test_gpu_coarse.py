@@ -36,20 +36,44 @@ def _nonsym3d(m):
     return rp, ci, v
 
 
-@pytest.mark.parametrize("name,gen", [
-    ("p3d_24", lambda: problems.poisson3d(24)),          # 13 824 rows, bandwidth ~ 24^2
-    ("p2d_150", lambda: problems.poisson2d(150)),        # 22 500 rows, narrow band -> blocks padded to 1024 wide
-    ("nonsym3d_22", lambda: _nonsym3d(22)),              # pivoting inside the diagonal blocks
-    ("p3d_ragged_last_block", lambda: problems.poisson3d(21)),  # 9261 rows: short last block
+def _nonsym2d(m):
+    rp, ci, v = problems.poisson2d(m)
+    rows = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
+    v = v.copy()
+    v[ci > rows] *= 0.9   # (weaker, not stronger, upper couplings: keeps the operator diagonally dominant)
+    d = ci == rows
+    v[d] += 0.02 * (rows[d] % 7)
+    return rp, ci, v
+
+
+@pytest.mark.parametrize("name,gen,interface", [
+    ("p3d_24", lambda: problems.poisson3d(24), True),          # 13 824 rows, bandwidth ~ 24^2: too wide for the interface form
+    ("p2d_150", lambda: problems.poisson2d(150), True),        # 22 500 rows, narrow band -> wide blocks, interface form of the solve
+    ("p2d_150_plain_chain", lambda: problems.poisson2d(150), False),  # the same through the plain chain of B x B steps
+    ("p2d_100_chain_unrolled", lambda: problems.poisson2d(100), True),        # window 128: each chain pass is one triangular product
+    ("p2d_100_chain_step_by_step", lambda: problems.poisson2d(100), 2),       # the same, one launch per chain step
+    ("nonsym2d_60_window64_short_last_block", lambda: _nonsym2d(60), True),   # window 64, last block (16 rows) shorter than a window
+    ("nonsym2d_170", lambda: _nonsym2d(170), True),
+    ("nonsym2d_170_chain_step_by_step", lambda: _nonsym2d(170), 2),            # 28 900 rows: interface form, pivoting, last block (100 rows) shorter than a window
+    ("nonsym3d_22", lambda: _nonsym3d(22), True),              # pivoting inside the diagonal blocks
+    ("p3d_ragged_last_block", lambda: problems.poisson3d(21), True),  # 9261 rows: short last block
 ])
-def test_block_tridiagonal_solver_vs_sparse_lu(name, gen):
+def test_block_tridiagonal_solver_vs_sparse_lu(name, gen, interface):
     rp, ci, v = gen()
     n = len(rp) - 1
-    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET, **ONE_LEVEL, dense_limit=2000))
+    A = sa.sp_matrix_mg(rp, ci, v).set_coarse_interface(interface).setup(sa.default_params(**QUIET, **ONE_LEVEL, dense_limit=2000))
     try:
         info = A.coarse_info()
         assert A.nlevels == 1 and info["rows"] == n and not info["dense"]
         assert info["nblocks"] >= 2 and info["block"] % 64 == 0 and info["block"] >= info["bandwidth"]
+        narrow = 2 * ((info["bandwidth"] + 63) // 64 * 64) <= info["block"]
+        assert (info["window"] > 0) == bool(narrow and interface), info
+        if "p2d_100" in name:
+            assert info["window"] == 128
+        if "window64" in name:
+            assert info["window"] == 64
+        if "2d" in name:
+            assert narrow
         S = sp.csr_matrix((v, ci, rp), shape=(n, n))
         lu = spla.splu(S.tocsc())
         rng = np.random.default_rng(1)

@@ -60,24 +60,41 @@ def run(name, rp, ci, v, methods, rhs="ones", **params):
 
 def main():
     res = {}
-    res["C2D_poisson2d_1000"] = run("C2D", *problems.poisson2d(1000), ["amg", "pcg"])  # default: the reference's 6 levels + block-tridiagonal direct solve
-    res["C2D_poisson2d_1000_extended_hierarchy"] = run("C2D ext", *problems.poisson2d(1000), ["amg", "pcg"], coarse_limit=8192)
-    res["C3D_poisson3d_100"] = run("100^3", *problems.poisson3d(100), ["amg", "pcg"])
-    res["C3D_poisson3d_100_extended_hierarchy"] = run("100^3 ext", *problems.poisson3d(100), ["amg", "pcg"], coarse_limit=8192)
-    res["C3D_poisson3d_216"] = run("C3D", *problems.poisson3d(216), ["amg", "pcg"])
-    res["C3D_poisson3d_216_10_levels_block_tridiagonal"] = run("C3D 10 levels", *problems.poisson3d(216), ["amg", "pcg"], max_levels=10, coarse_limit=1 << 30)
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]  # substrings of case names to run (default: all)
+
+    def want(name):
+        return not only or any(o in name for o in only)
+    if want("C2D_poisson2d_1000"):
+        res["C2D_poisson2d_1000"] = run("C2D", *problems.poisson2d(1000), ["amg", "pcg"])  # default: the reference's 6 levels + block-tridiagonal direct solve
+    if want("C2D_poisson2d_1000_extended_hierarchy"):
+        res["C2D_poisson2d_1000_extended_hierarchy"] = run("C2D ext", *problems.poisson2d(1000), ["amg", "pcg"], coarse_limit=8192)
+    if want("C3D_poisson3d_100"):
+        res["C3D_poisson3d_100"] = run("100^3", *problems.poisson3d(100), ["amg", "pcg"])
+    if want("C3D_poisson3d_100_extended_hierarchy"):
+        res["C3D_poisson3d_100_extended_hierarchy"] = run("100^3 ext", *problems.poisson3d(100), ["amg", "pcg"], coarse_limit=8192)
+    if want("C3D_poisson3d_216"):
+        res["C3D_poisson3d_216"] = run("C3D", *problems.poisson3d(216), ["amg", "pcg"])
+    if want("C3D_poisson3d_216_10_levels_block_tridiagonal"):
+        res["C3D_poisson3d_216_10_levels_block_tridiagonal"] = run("C3D 10 levels", *problems.poisson3d(216), ["amg", "pcg"], max_levels=10, coarse_limit=1 << 30)
     # nu = 6 sweeps: what the reference's GPU path effectively runs (smooth_iter without the +1 of the CPU path)
-    res["C3D_poisson3d_216_nu6"] = run("C3D nu=6", *problems.poisson3d(216), ["amg", "pcg"], sweeps=6)
+    if want("C3D_poisson3d_216_nu6"):
+        res["C3D_poisson3d_216_nu6"] = run("C3D nu=6", *problems.poisson3d(216), ["amg", "pcg"], sweeps=6)
     # Beck's classical C/F interpolation instead of HEM aggregation (general multi-entry P and R, denser
     # coarse operators: CSR-stream / sliced-ELL kernels on the coarse levels)
-    res["C3D_poisson3d_100_beck"] = run("C3D 100^3 Beck", *problems.poisson3d(100), ["amg", "pcg"], coarsening=1)
-    res["C2D_poisson2d_1000_beck"] = run("C2D Beck", *problems.poisson2d(1000), ["amg", "pcg"], coarsening=1)
-    res["C3D_poisson3d_216_beck"] = run("C3D 216^3 Beck", *problems.poisson3d(216), ["amg", "pcg"], coarsening=1)
+    if want("C3D_poisson3d_100_beck"):
+        res["C3D_poisson3d_100_beck"] = run("C3D 100^3 Beck", *problems.poisson3d(100), ["amg", "pcg"], coarsening=1)
+    if want("C2D_poisson2d_1000_beck"):
+        res["C2D_poisson2d_1000_beck"] = run("C2D Beck", *problems.poisson2d(1000), ["amg", "pcg"], coarsening=1)
+    if want("C3D_poisson3d_216_beck"):
+        res["C3D_poisson3d_216_beck"] = run("C3D 216^3 Beck", *problems.poisson3d(216), ["amg", "pcg"], coarsening=1)
     mtx = os.environ.get("SPARSH_MTX")  # e.g. SuiteSparse parabolic_fem.mtx when it is on the box
     if mtx and os.path.exists(mtx):
-        res["CU_" + os.path.basename(mtx)] = run("CU file", *problems.read_matrix_market(mtx), ["pbicg", "pcg"])
-    res["CU_fem_unstructured_525825"] = run("CU", *problems.fem_unstructured(), ["pbicg", "pcg"], rhs="random")
-    res["CU_fem_unstructured_60000"] = run("CU60k", *problems.fem_unstructured(60000, seed=7), ["pbicg", "pcg"], rhs="random")
+        if want("CU_"):
+            res["CU_" + os.path.basename(mtx)] = run("CU file", *problems.read_matrix_market(mtx), ["pbicg", "pcg"])
+    if want("CU_fem_unstructured_525825"):
+        res["CU_fem_unstructured_525825"] = run("CU", *problems.fem_unstructured(), ["pbicg", "pcg"], rhs="random")
+    if want("CU_fem_unstructured_60000"):
+        res["CU_fem_unstructured_60000"] = run("CU60k", *problems.fem_unstructured(60000, seed=7), ["pbicg", "pcg"], rhs="random")
     print(json.dumps(res, indent=1))
 
 
