@@ -202,6 +202,9 @@ int sparsh_coarse_info(sparsh_handle h, int *info6, long *bytes);
  * described, 2 the interface form with one launch per chain step (A/B measurements). */
 int sparsh_coarse_window(sparsh_handle h, int *window);
 int sparsh_set_coarse_interface(sparsh_handle h, int enable);
+/* Block size of the block-tridiagonal coarse factorisation: rows > 0 before sparsh_setup replaces the built-in rule
+ * (rounded up to 64 and never below the RCM bandwidth); 0 restores the rule.  A/B measurements. */
+int sparsh_set_coarse_block(sparsh_handle h, int rows);
 double sparsh_setup_seconds(sparsh_handle h);
 
 /* AMG_solver::AMG_solve_jacobi(b, x, iterations) (src/AMG_phases.cpp:151-230) ==

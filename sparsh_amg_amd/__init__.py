@@ -103,6 +103,7 @@ def _load():
         "sparsh_coarse_info": (C.c_int, [H, c_int_p, C.POINTER(C.c_long)]),
         "sparsh_coarse_window": (C.c_int, [H, c_int_p]),
         "sparsh_set_coarse_interface": (C.c_int, [H, C.c_int]),
+        "sparsh_set_coarse_block": (C.c_int, [H, C.c_int]),
         "sparsh_setup_seconds": (C.c_double, [H]),
         "sparsh_vcycle": (C.c_int, [H, c_dbl_p, c_dbl_p, C.c_int, c_dbl_p, C.c_int, c_int_p]),
         "sparsh_vcycle_dev": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int, c_dbl_p, C.c_int, c_int_p]),
@@ -384,6 +385,11 @@ class sp_matrix_mg:
         _check(lib.sparsh_coarse_window(self._h, C.byref(win)))
         return {"rows": info[0], "dense": bool(info[1]), "block": info[2], "nblocks": info[3], "bandwidth": info[4],
                 "extended": bool(info[5]), "bytes": nbytes.value, "window": win.value}
+
+    def set_coarse_block(self, rows=0):
+        """Block size of the block-tridiagonal coarse factorisation (0 = built-in rule); call before setup."""
+        _check(lib.sparsh_set_coarse_block(self._h, int(rows)))
+        return self
 
     def set_coarse_interface(self, enable=True):
         """Interface (window) form of the block-tridiagonal coarse solve, default on; call before setup."""

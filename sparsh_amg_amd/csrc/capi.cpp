@@ -427,6 +427,14 @@ int sparsh_set_coarse_interface(sparsh_handle h, int enable)
     return SPARSH_OK;
 }
 
+int sparsh_set_coarse_block(sparsh_handle h, int rows)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    if (rows < 0) return fail(SPARSH_EINVAL, "rows must be >= 0 (0 = built-in rule)");
+    h->eng->coarse_mut().set_block_hint(rows);
+    return SPARSH_OK;
+}
+
 int sparsh_coarse_window(sparsh_handle h, int *window)
 {
     REQUIRE_HOST(h);

@@ -27,7 +27,7 @@ HostCsr make_csr(int n, std::vector<int> &&rp, std::vector<int> &&ci, std::vecto
 
 }  // namespace
 
-bool bt_make_plan(const HostCsr &A, int target_blocks, int max_block, BtPlan &P, std::string &err)
+bool bt_make_plan(const HostCsr &A, int target_blocks, int max_block, BtPlan &P, std::string &err, int block_hint)
 {
     const int n = A.nrow;
     P = BtPlan();
@@ -43,6 +43,7 @@ bool bt_make_plan(const HostCsr &A, int target_blocks, int max_block, BtPlan &P,
     // any B >= bandwidth makes the permuted operator block tridiagonal.  Narrow-band operators (2D
     // grids) take wider blocks, up to 1024, so the chain of dependent steps stays short.
     int B = std::max(up64(std::max(bw, 1)), std::min(up64((n + target_blocks - 1) / std::max(1, target_blocks)), 1024));
+    if (block_hint > 0) B = std::max(up64(std::max(bw, 1)), up64(block_hint));
     if (B > max_block) {
         err = "coarsest level too wide for the block-tridiagonal device solve: bandwidth " + std::to_string(bw) + " after RCM (limit " +
               std::to_string(max_block) + "); lower coarse_limit so the hierarchy is extended instead";
@@ -187,7 +188,7 @@ bool CoarseSolver::setup_bt(const HostCsr &A, hipStream_t st, std::string &err, 
     int &why = why_failed ? *why_failed : why_local;
     why = 3;
     const auto t0 = std::chrono::steady_clock::now();
-    if (!bt_make_plan(A, 32, 6144, plan_, err)) {
+    if (!bt_make_plan(A, 32, 6144, plan_, err, block_hint_)) {
         why = 1;
         return false;
     }

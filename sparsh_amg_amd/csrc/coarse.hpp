@@ -46,7 +46,8 @@ struct BtPlan {
 };
 
 // false when the operator cannot take this form (bandwidth above max_block)
-bool bt_make_plan(const HostCsr &A, int target_blocks, int max_block, BtPlan &plan, std::string &err);
+// block_hint > 0: use blocks of that many rows (rounded up to 64, at least the bandwidth) instead of the built-in rule
+bool bt_make_plan(const HostCsr &A, int target_blocks, int max_block, BtPlan &plan, std::string &err, int block_hint = 0);
 
 class CoarseSolver {
 public:
@@ -72,6 +73,7 @@ public:
     int bandwidth() const { return plan_.bw; }
     bool windowed() const { return windowed_; }
     int window() const { return win_; }
+    void set_block_hint(int rows) { block_hint_ = rows; }  // before setup_bt; 0 = built-in rule
     void set_allow_windowed(bool on) { allow_windowed_ = on; }  // before setup_bt (A/B measurements)
     void set_unrolled_chain(bool on) { unroll_chain_ = on; }  // interface form: chain passes as triangular products (default) or step by step
     bool unrolled() const { return unrolled_; }
@@ -81,6 +83,7 @@ public:
 
 private:
     bool allow_windowed_ = true, unroll_chain_ = true;
+    int block_hint_ = 0;
     int n_ = 0;
     bool dense_ = true;
     double *inv_ = nullptr;  // dense form

@@ -22,7 +22,10 @@ from sparsh_amg_amd import problems
 def run(name, rp, ci, v, methods, rhs="ones", **params):
     n = len(rp) - 1
     out = {"rows": n, "nnz": int(rp[-1])}
-    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, print_solve=0, **params))
+    A = sa.sp_matrix_mg(rp, ci, v)
+    if os.environ.get("SPARSH_COARSE_BLOCK"):  # A/B of the block-tridiagonal coarse solver's block size
+        A.set_coarse_block(int(os.environ["SPARSH_COARSE_BLOCK"]))
+    A.setup(sa.default_params(print_setup=0, print_solve=0, **params))
     out["levels"] = [A.level_info(l)["nrow"] for l in range(A.nlevels)]
     out["level_kernels"] = [A.level_kernel(l) for l in range(A.nlevels - 1)]
     out["coarsest"] = A.coarse_info()
