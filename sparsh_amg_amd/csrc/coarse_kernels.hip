@@ -478,28 +478,43 @@ struct BtTri {
 };
 
 // dst[idx[r]] = sum_c M[r][c] src[idx[c]] over the columns of the triangle: lower: c < (r / W + 1) W; upper: (r / W) W <= c < ld.
-// blockIdx.y = chain; one wave per row.
+// blockIdx.y = chain; a workgroup takes 4 consecutive rows (one per wave; same row block, W is a multiple of 64) and first
+// gathers the vector segment they share into LDS, so the row loads (4 in flight per lane) depend on nothing.
 __global__ __launch_bounds__(kCB) void bt_tri_gemv_kernel(BtTri t, int W, int lower, const double *__restrict__ src, double *__restrict__ dst)
 {
+    extern __shared__ double v[];
     const int c = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * (kCB / 64) + (threadIdx.x >> 6);
-    if (r >= t.rows[c]) return;
+    const int r0 = blockIdx.x * (kCB / 64);
+    if (r0 >= t.rows[c]) return;  // whole workgroup
     const int *__restrict__ idx = t.idx[c];
+    const int ld = t.ld[c];
+    const int k = r0 / W;
+    const int c0 = lower ? 0 : k * W, c1 = lower ? (k + 1) * W : ld;
+    for (int j = c0 + threadIdx.x; j < c1; j += kCB) {
+        const int ix = idx[j];
+        v[j - c0] = ix >= 0 ? src[ix] : 0.0;
+    }
+    __syncthreads();
+    const int r = r0 + (threadIdx.x >> 6);
+    if (r >= t.rows[c]) return;
     const int out = idx[r];
     if (out < 0) return;  // padding row of a short block
-    const int ld = t.ld[c];
     const double *__restrict__ row = t.M[c] + (size_t)r * ld;
-    const int k = r / W;
-    const int c0 = lower ? 0 : k * W, c1 = lower ? (k + 1) * W : ld;
-    double acc = 0.0;
-    for (int j = c0 + lane; j < c1; j += 64) {
-        const double m = row[j];
-        const int ix = idx[j];
-        const double v = ix >= 0 ? src[ix] : 0.0;
-        acc += m != 0.0 ? m * v : 0.0;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int j = c0 + lane; j < c1; j += 256) {
+        const int j1 = j + 64, j2 = j + 128, j3 = j + 192;
+        const double m0 = row[j];
+        const double m1 = j1 < c1 ? row[j1] : 0.0;
+        const double m2 = j2 < c1 ? row[j2] : 0.0;
+        const double m3 = j3 < c1 ? row[j3] : 0.0;
+        // structural zeros must not pick up a NaN a broken-down solve left behind
+        a0 += m0 != 0.0 ? m0 * v[j - c0] : 0.0;
+        a1 += m1 != 0.0 ? m1 * v[j1 - c0] : 0.0;
+        a2 += m2 != 0.0 ? m2 * v[j2 - c0] : 0.0;
+        a3 += m3 != 0.0 ? m3 * v[j3 - c0] : 0.0;
     }
-    acc = wsum(acc);
+    const double acc = wsum((a0 + a1) + (a2 + a3));
     if (lane == 0) dst[out] = acc;
 }
 
@@ -536,21 +551,46 @@ __global__ __launch_bounds__(kCB) void bt_win_mid_kernel(int B, int n, int W, in
     }
 }
 
-// all rows of all blocks: x[perm[r]] = y[r] - G zw[gwin] - H (block == mid ? zw : xw)[hwin]; one wave per row
+// all rows of all blocks: x[perm[r]] = y[r] - G zw[gwin] - H (block == mid ? zw : xw)[hwin].  A wave takes kFinalRows consecutive
+// rows (same block: B is a multiple of 64) so that all their G / H loads are in flight before the first reduction.
+constexpr int kFinalRows = 4;
+
 __global__ __launch_bounds__(kCB) void bt_win_final_kernel(int B, int n, int W, int mid, const int *__restrict__ wdesc, const double *__restrict__ g,
                                                            const double *__restrict__ h, const double *__restrict__ y, const double *__restrict__ zw,
                                                            const double *__restrict__ xw, const int *__restrict__ perm, double *__restrict__ x)
 {
     const int lane = threadIdx.x & 63;
-    const int gr = blockIdx.x * (kCB / 64) + (threadIdx.x >> 6);
-    if (gr >= n) return;
-    const int blk = gr / B;
+    const int gr0 = (blockIdx.x * (kCB / 64) + (threadIdx.x >> 6)) * kFinalRows;
+    if (gr0 >= n) return;
+    const int blk = gr0 / B;
     const int gwin0 = wdesc[4 * blk], gwn = wdesc[4 * blk + 1], hwin0 = wdesc[4 * blk + 2], hwn = wdesc[4 * blk + 3];
-    const size_t ro = (size_t)gr * W;  // = (blk * B + local row) * W
-    double val = y[gr];
-    if (gwn > 0) val -= win_dot(g + ro, zw + gwin0, gwn, W, lane);
-    if (hwn > 0) val -= win_dot(h + ro, (blk == mid ? zw : xw) + hwin0, hwn, W, lane);
-    if (lane == 0) x[perm[gr]] = val;
+    const double *__restrict__ hv = (blk == mid ? zw : xw) + hwin0;
+    const double *__restrict__ gv = zw + gwin0;
+    double acc[kFinalRows];
+#pragma unroll
+    for (int q = 0; q < kFinalRows; ++q) acc[q] = 0.0;
+    for (int c = lane; c < W; c += 64) {
+        const double tg = c < gwn ? gv[c] : 0.0;
+        const double th = c < hwn ? hv[c] : 0.0;
+        double mg[kFinalRows], mh[kFinalRows];
+#pragma unroll
+        for (int q = 0; q < kFinalRows; ++q) {
+            const bool on = gr0 + q < n;
+            const size_t ro = (size_t)(gr0 + q) * W + c;
+            mg[q] = on ? g[ro] : 0.0;
+            mh[q] = on ? h[ro] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < kFinalRows; ++q) {
+            acc[q] += mg[q] != 0.0 ? mg[q] * tg : 0.0;
+            acc[q] += mh[q] != 0.0 ? mh[q] * th : 0.0;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kFinalRows; ++q) {
+        const double d = wsum(acc[q]);
+        if (lane == 0 && gr0 + q < n) x[perm[gr0 + q]] = y[gr0 + q] - d;
+    }
 }
 
 __global__ __launch_bounds__(kCB) void cvt_f2d_kernel(int n, const float *__restrict__ in, double *__restrict__ out)
@@ -657,7 +697,8 @@ void bt_launch_tri_gemv(const double *const M[2], const int *const idx[2], const
         mx = rows[c] > mx ? rows[c] : mx;
     }
     if (mx <= 0) return;
-    hipLaunchKernelGGL(bt_tri_gemv_kernel, dim3((mx + kCB / 64 - 1) / (kCB / 64), 2), dim3(kCB), 0, st, t, W, lower, src, dst);
+    const int ldmax = ld[0] > ld[1] ? ld[0] : ld[1];
+    hipLaunchKernelGGL(bt_tri_gemv_kernel, dim3((mx + kCB / 64 - 1) / (kCB / 64), 2), dim3(kCB), (size_t)ldmax * sizeof(double), st, t, W, lower, src, dst);
 }
 
 void bt_launch_win_mid(int nb, int B, int n, int W, int mid, const int *wdesc, const double *g, const double *h, const double *y, double *zw,
@@ -671,7 +712,8 @@ void bt_launch_win_final(int nb, int B, int n, int W, int mid, const int *wdesc,
                          const double *zw, const double *xw, const int *perm, double *x, hipStream_t st)
 {
     (void)nb;
-    hipLaunchKernelGGL(bt_win_final_kernel, dim3((n + kCB / 64 - 1) / (kCB / 64)), dim3(kCB), 0, st, B, n, W, mid, wdesc, g, h, y, zw, xw, perm, x);
+    const int per_wg = (kCB / 64) * kFinalRows;
+    hipLaunchKernelGGL(bt_win_final_kernel, dim3((n + per_wg - 1) / per_wg), dim3(kCB), 0, st, B, n, W, mid, wdesc, g, h, y, zw, xw, perm, x);
 }
 
 void launch_cvt_f2d(int n, const float *in, double *out, hipStream_t st)
