@@ -88,6 +88,7 @@ def _load():
         "sparsh_set_const_slots": (C.c_int, [H, C.c_int]),
         "sparsh_set_tile": (C.c_int, [H, C.c_int]),
         "sparsh_set_index_compression": (C.c_int, [H, C.c_int]),
+        "sparsh_set_alternate_sweeps": (C.c_int, [H, C.c_int]),
         "sparsh_set_setup_broadcast": (C.c_int, [H, C.c_int]),
         "sparsh_debug_hierarchy_roundtrip": (C.c_long, [H, C.c_long]),
         "sparsh_setup_share_info": (C.c_int, [H, C.POINTER(C.c_int), C.POINTER(C.c_long)]),
@@ -274,6 +275,11 @@ class sp_matrix_mg:
         a, b = C.c_int(), C.c_long()
         _check(lib.sparsh_setup_share_info(self._h, C.byref(a), C.byref(b)))
         return bool(a.value), b.value
+
+    def set_alternate_sweeps(self, enable=True):
+        """Alternate the walking direction of consecutive sweeps of a smoothing leg (default on); any time."""
+        _check(lib.sparsh_set_alternate_sweeps(self._h, int(bool(enable))))
+        return self
 
     def set_index_compression(self, mode=1):
         """16-bit delta-coded column indices for the CSR-stream family (call before setup); see sparsh_set_index_compression."""

@@ -342,6 +342,13 @@ long sparsh_debug_hierarchy_roundtrip(sparsh_handle h, long truncate_to)
     return (long)img.size();
 }
 
+int sparsh_set_alternate_sweeps(sparsh_handle h, int enable)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    h->eng->kernel_cfg().alt_dir = enable != 0;
+    return SPARSH_OK;
+}
+
 int sparsh_set_index_compression(sparsh_handle h, int mode)
 {
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
@@ -911,6 +918,7 @@ int sparsh_bench_op(sparsh_handle h, int op, int level, int reps, double *avg_se
             a.b = op == 9 ? b.p : L.r;
             a.d = L.diag;
             a.omega = E.params().omega;
+            a.reverse = E.kernel_cfg().alt_dir && (flip & 1);
             ++flip;
             launch_csr(L.A, OP_JACOBI, a, L.fine, st, E.kernel_cfg());
         } break;

@@ -1143,6 +1143,7 @@ void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, doubl
             a.d = L.diag;
             a.y = L.x2;
             a.omega = prm_.omega;
+            a.reverse = cfg_.alt_dir && (in_run & 1) == 0;  // first sweep of the run against the (ascending) kernel before it, then alternating
             const int depth_left = std::max(K - (s + 1), 0);  // this is sweep s+1: it updates the layers <= K-(s+1)
             launch_prefix(L, L.layer_end[depth_left], OP_JACOBI, a);
             ++in_run;
@@ -1173,6 +1174,7 @@ void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, doubl
         a.d = L.diag;
         a.y = L.x2;
         a.omega = prm_.omega;
+        a.reverse = cfg_.alt_dir && (in_run & 1) == 0;  // first sweep of the run against the (ascending) kernel before it, then alternating
         CsrOp op = OP_JACOBI;
         if (last && dot_partial) {
             op = OP_JACOBI_DOT;

@@ -260,7 +260,8 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(const int *__restrict
 {
     __shared__ double prod[kStreamNnz];
     __shared__ double red[kBlock / 64];
-    const int bid = remap ? xcd_remap(blockIdx.x, nblk, remap) : blockIdx.x;
+    int bid = remap ? xcd_remap(blockIdx.x, nblk, remap) : blockIdx.x;
+    if (a.reverse && bid < nblk) bid = nblk - 1 - bid;
     if (bid >= nblk) return;  // whole workgroup leaves together
     const int tid = threadIdx.x;
     // one 16-byte record per block {first row, end row, first entry, end entry}: the stream loads start one
@@ -408,7 +409,8 @@ __device__ __forceinline__ void csr_rowlane_body(const int *__restrict__ rowblk,
     __shared__ __attribute__((aligned(16))) double sval[kStreamNnz + 2];  // + 2: the run is staged from the even index at or below j0
     __shared__ __attribute__((aligned(16))) int scol[kStreamNnz + 2];
     __shared__ double red[kBlock / 64];
-    const int bid = remap ? xcd_remap(blockIdx.x, nblk, remap) : blockIdx.x;
+    int bid = remap ? xcd_remap(blockIdx.x, nblk, remap) : blockIdx.x;
+    if (a.reverse && bid < nblk) bid = nblk - 1 - bid;
     if (bid >= nblk) return;  // whole workgroup leaves together
     const int tid = threadIdx.x;
     const int4 br = reinterpret_cast<const int4 *>(rowblk)[bid];
@@ -483,7 +485,8 @@ __global__ __launch_bounds__(kBlock) void csr_wave_kernel(const int *__restrict_
 {
     __shared__ double prod_all[kBlock / 64][kWaveNnz];
     __shared__ double red[kBlock / 64];
-    const int gid = remap ? xcd_remap(blockIdx.x, ngroups, remap) : blockIdx.x;  // group of 4 wave-blocks
+    int gid = remap ? xcd_remap(blockIdx.x, ngroups, remap) : blockIdx.x;  // group of 4 wave-blocks
+    if (a.reverse && gid < ngroups) gid = ngroups - 1 - gid;
     if (gid >= ngroups) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wb = gid * (kBlock / 64) + w;
@@ -581,7 +584,8 @@ __global__ __launch_bounds__(kBlock) void sell_kernel(int nrow, int nslice, int 
                                                        const int *__restrict__ scol, const double *__restrict__ sval, CsrArgs a)
 {
     __shared__ double red[kBlock / 64];
-    const int gid = remap ? xcd_remap(blockIdx.x, ngroups, remap) : blockIdx.x;
+    int gid = remap ? xcd_remap(blockIdx.x, ngroups, remap) : blockIdx.x;
+    if (a.reverse && gid < ngroups) gid = ngroups - 1 - gid;
     if (gid >= ngroups) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int idx = gid * (kBlock / 64) + w;
@@ -842,7 +846,8 @@ __global__ __launch_bounds__(kBlock) void sdia_kernel(int nrow, int nslice, int 
                                                        const double *__restrict__ sd_val, const int *__restrict__ sd_rec, CsrArgs a)
 {
     __shared__ double red[kBlock / 64];
-    const int gid = remap ? xcd_remap(blockIdx.x, ngroups, remap) : blockIdx.x;
+    int gid = remap ? xcd_remap(blockIdx.x, ngroups, remap) : blockIdx.x;
+    if (a.reverse && gid < ngroups) gid = ngroups - 1 - gid;
     if (gid >= ngroups) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int idx = __builtin_amdgcn_readfirstlane(gid * (kBlock / 64) + w);  // wave-uniform: keeps the slice metadata on the scalar path
@@ -1004,7 +1009,8 @@ __global__ __launch_bounds__(kBlock) void sdia_tab_kernel(int nrow, int xlen, in
                                                            const int *__restrict__ sd_rec, CsrArgs a)
 {
     __shared__ double red[kBlock / 64];
-    const int gid = remap ? xcd_remap(blockIdx.x, ngroups, remap) : blockIdx.x;
+    int gid = remap ? xcd_remap(blockIdx.x, ngroups, remap) : blockIdx.x;
+    if (a.reverse && gid < ngroups) gid = ngroups - 1 - gid;
     if (gid >= ngroups) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int idx = __builtin_amdgcn_readfirstlane(gid * (kBlock / 64) + w);
@@ -1084,7 +1090,8 @@ __global__ __launch_bounds__(kTileBlock) void sdia_tile_kernel(int nrow, int xle
     constexpr int C0 = ND / 2;
     constexpr int T = kTileBlock * S;
     constexpr int NW = kTileBlock / 64;
-    const int tile = remap ? xcd_remap(blockIdx.x, ntile, remap) : blockIdx.x;
+    int tile = remap ? xcd_remap(blockIdx.x, ntile, remap) : blockIdx.x;
+    if (a.reverse && tile < ntile) tile = ntile - 1 - tile;
     if (tile >= ntile) return;  // whole workgroup leaves together
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int lo = -tab.off[C0 - 2], hi = tab.off[C0 + 2];  // reach of the +-line neighbours (kernel arguments)

@@ -94,6 +94,7 @@ struct KernelConfig {
     bool table = true;  // use the level-wide stencil table where a level has one
     bool tile = false;  // table levels of grid stencils: stage x tiles in LDS (sdia_tile_kernel) on whole-level launches
     bool const_slots = true;  // layout option read at setup: fold constant diagonals of a slice into one scalar
+    bool alt_dir = true;      // consecutive sweeps of a smoothing leg walk the level in alternating directions (CsrArgs::reverse)
     int idx16 = 1;      // layout option read at setup: build the 16-bit delta column form (DevCsr::col16) for 0 no operator,
                         // 1 operators whose default family is the CSR-stream kernel streaming from HBM, 2 every operator
 };
@@ -134,6 +135,9 @@ struct CsrArgs {
     const int *slice_list = nullptr;
     int nlist = 0;
     int partial_off = 0;
+    // walk the row blocks / slices from the last to the first: consecutive sweeps of a smoothing leg alternate, so a sweep starts on
+    // the part of the iterate the previous one wrote last (still in the memory-side cache); placement only, results unchanged
+    int reverse = 0;
 };
 
 // host-side builder of the row-block schedule (returns number of blocks; out sized nrow+1 max)
