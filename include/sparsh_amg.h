@@ -142,10 +142,12 @@ int sparsh_set_const_slots(sparsh_handle h, int enable);
  * 2 for every operator (A/B measurements with sparsh_set_kernel_config(h, 0, 4, ...)).
  * sparsh_level_index16: how many row blocks of a level's operator use the 16-bit form, out of how many. */
 int sparsh_set_index_compression(sparsh_handle h, int mode);
-/* Consecutive Jacobi sweeps of a smoothing leg walk the level's row blocks in alternating directions (default on): a sweep
- * starts on the part of the iterate the previous one wrote last, which is still in the memory-side cache.  Placement
- * only -- every row is computed exactly as before.  sparsh_set_alternate_sweeps(h, 0): always ascending (A/B). */
-int sparsh_set_alternate_sweeps(sparsh_handle h, int enable);
+/* Consecutive Jacobi sweeps of a smoothing leg may walk the level's row blocks in alternating directions: a sweep then starts
+ * on the part of the vectors the previous one touched last, which is still in the memory-side cache.  Placement only -- every
+ * row is computed exactly as before.  mode 0: always ascending; 1 (default): alternate where one sweep streams more than
+ * 640 MB = 2.5x the Infinity Cache (matrix-streaming layouts of large levels: -3...6 % per sweep; smaller levels and the
+ * value-free table path measured neutral within +-1 %); 2: always alternate (A/B). */
+int sparsh_set_alternate_sweeps(sparsh_handle h, int mode);
 /* Multi-GPU setup: by default rank 0 alone runs the host setup (coarsening, Galerkin products, coarse factor) and the other
  * ranks receive the finished hierarchy through the transport (one RCCL broadcast of its byte image, staged through HBM in
  * 256 MB pieces) instead of repeating the identical setup N times; every rank then cuts out and uploads its own row

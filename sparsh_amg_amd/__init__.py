@@ -276,9 +276,9 @@ class sp_matrix_mg:
         _check(lib.sparsh_setup_share_info(self._h, C.byref(a), C.byref(b)))
         return bool(a.value), b.value
 
-    def set_alternate_sweeps(self, enable=True):
-        """Alternate the walking direction of consecutive sweeps of a smoothing leg (default on); any time."""
-        _check(lib.sparsh_set_alternate_sweeps(self._h, int(bool(enable))))
+    def set_alternate_sweeps(self, mode=1):
+        """Alternate the walking direction of consecutive sweeps of a smoothing leg: 0 never, 1 large streaming levels (default), 2 always."""
+        _check(lib.sparsh_set_alternate_sweeps(self._h, int(mode)))
         return self
 
     def set_index_compression(self, mode=1):

@@ -345,7 +345,8 @@ long sparsh_debug_hierarchy_roundtrip(sparsh_handle h, long truncate_to)
 int sparsh_set_alternate_sweeps(sparsh_handle h, int enable)
 {
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
-    h->eng->kernel_cfg().alt_dir = enable != 0;
+    if (enable < 0 || enable > 2) return fail(SPARSH_EINVAL, "mode must be 0 (never), 1 (where a sweep streams more than the Infinity Cache holds) or 2 (always)");
+    h->eng->kernel_cfg().alt_dir = enable;
     return SPARSH_OK;
 }
 
@@ -918,7 +919,7 @@ int sparsh_bench_op(sparsh_handle h, int op, int level, int reps, double *avg_se
             a.b = op == 9 ? b.p : L.r;
             a.d = L.diag;
             a.omega = E.params().omega;
-            a.reverse = E.kernel_cfg().alt_dir && (flip & 1);
+            a.reverse = csr_alternates(L.A, E.kernel_cfg()) && (flip & 1);
             ++flip;
             launch_csr(L.A, OP_JACOBI, a, L.fine, st, E.kernel_cfg());
         } break;

@@ -1143,7 +1143,7 @@ void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, doubl
             a.d = L.diag;
             a.y = L.x2;
             a.omega = prm_.omega;
-            a.reverse = cfg_.alt_dir && (in_run & 1) == 0;  // first sweep of the run against the (ascending) kernel before it, then alternating
+            a.reverse = csr_alternates(L.A, cfg_) && (in_run & 1) == 0;  // first sweep of the run against the (ascending) kernel before it, then alternating
             const int depth_left = std::max(K - (s + 1), 0);  // this is sweep s+1: it updates the layers <= K-(s+1)
             launch_prefix(L, L.layer_end[depth_left], OP_JACOBI, a);
             ++in_run;
@@ -1174,7 +1174,7 @@ void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, doubl
         a.d = L.diag;
         a.y = L.x2;
         a.omega = prm_.omega;
-        a.reverse = cfg_.alt_dir && (in_run & 1) == 0;  // first sweep of the run against the (ascending) kernel before it, then alternating
+        a.reverse = csr_alternates(L.A, cfg_) && (in_run & 1) == 0;  // first sweep of the run against the (ascending) kernel before it, then alternating
         CsrOp op = OP_JACOBI;
         if (last && dot_partial) {
             op = OP_JACOBI_DOT;
@@ -1208,7 +1208,7 @@ void Engine::op_jacobi(int l, const double *b, double *x, double *tmp, int sweep
 }
 
 // One V(nu,nu) cycle (body of the while loops in AMG_solve_jacobi, src/AMG_phases.cpp:198-216).
-void Engine::vcycle(const double *b0, bool x0_zero, double *dot_partial, int *dot_nblk)
+void Engine::vcycle(const double *b0, bool x0_zero, double *dot_partial, int *dot_nblk, bool zero_done0)
 {
     const int last = (int)lev_.size() - 1;
     const int nu = prm_.sweeps;
@@ -1218,7 +1218,7 @@ void Engine::vcycle(const double *b0, bool x0_zero, double *dot_partial, int *do
         if (dot_partial) launch_dot(lev_[0].n, lev_[0].x, b0, dot_partial, dot_nblk, st_);
         return;
     }
-    bool zero_done = false;  // the previous level's restriction already wrote this level's zero-guess sweep
+    bool zero_done = zero_done0 && x0_zero;  // the previous level's restriction (level 0: the caller) already wrote this level's zero-guess sweep
     for (int l = 0; l < last; ++l) {
         DevLevel &L = lev_[l];
         if (L.deep) {
@@ -1347,7 +1347,12 @@ void Engine::pcg_body(bool precond, int slot)
     finalize(precond ? FIN_PCG_ALPHA : FIN_CG_ALPHA, part0_, nullptr, np, 0, nullptr, 0);
     // x += alpha p ; r -= alpha Ap ; r.r -- with a preconditioner the r.r partials wait in part1_ and
     // are reduced together with z.r after the V-cycle: one finalize launch (one all-reduce) less
-    launch_cg_update(n, scal_, p, Ap, x, r, precond ? part1_ : part0_, &nb, st_);
+    // with the fp64 V-cycle behind it the update also writes the cycle's zero-guess sweep of level 0 (z0 = omega r / d)
+    const bool fuse_zero = precond && !f32_ready_ && lev_.size() > 1 && !lev_[0].deep && prm_.sweeps > 0;
+    if (fuse_zero)
+        launch_cg_update_zero(n, scal_, p, Ap, x, r, part1_, &nb, lev_[0].diag, prm_.omega, lev_[0].x, st_);
+    else
+        launch_cg_update(n, scal_, p, Ap, x, r, precond ? part1_ : part0_, &nb, st_);
     if (precond && f32_ready_) {
         const int nb_rr = nb;
         vcycle_f32(r, work_[4], part0_, &nb);  // float hierarchy, fp64 in/out, fused z0.r0
@@ -1355,7 +1360,7 @@ void Engine::pcg_body(bool precond, int slot)
         launch_p_update(n, scal_, work_[4], p, st_);
     } else if (precond) {
         const int nb_rr = nb;
-        vcycle(r, true, part0_, &nb);  // z0 = 0 ; z0 = V(r0) ; fused z0.r0
+        vcycle(r, true, part0_, &nb, fuse_zero);  // z0 = 0 ; z0 = V(r0) ; fused z0.r0
         finalize(FIN_PCG_BETA_RES, part0_, part1_, nb, 0, hist_dev_, slot, nb_rr);
         launch_p_update(n, scal_, lev_[0].x, p, st_);  // p = z0 + beta p
     } else {

@@ -172,7 +172,7 @@ private:
     // one V(nu,nu) cycle: rhs b0 (device, read-only), solution accumulates in lev_[0].x.
     // x0_zero: the initial guess of level 0 is zero (preconditioner use).
     // dot_partial: when non-null the last post-sweep also leaves partial sums of x.b there.
-    void vcycle(const double *b0, bool x0_zero, double *dot_partial, int *dot_nblk);
+    void vcycle(const double *b0, bool x0_zero, double *dot_partial, int *dot_nblk, bool zero_done0 = false);
     // zero_done: the zero-guess sweep x = omega*b/d has already been written to L.x (fused into the restriction)
     void smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, double *dot_partial, int *dot_nblk, bool zero_done = false);
     bool halo(const DevPlan &p, double *vec);  // pack + exchange (no-op on one GPU)

@@ -1442,6 +1442,26 @@ CsrFamily csr_family(const DevCsr &A, const KernelConfig &c)
     return FAM_CSR_BLOCK;
 }
 
+// Alternating sweep direction pays where a sweep streams several times what the 256 MB memory-side cache holds: the next sweep
+// then starts on what is still cached instead of on what was evicted first.  Same-process A/B at 216^3 (tools/alt_dir_ab.py):
+// CSR-stream level 0 (1.1 GB per sweep) 189 -> 178 us, general sliced diagonals (0.83 GB) 139.5 -> 135.8 us; the 5 M-row
+// level 1 of both (0.4-0.56 GB) 1 % slower; the value-free table path (0.25 GB: fits) +-1 % depending on the box.  Hence the
+// threshold.  Bytes per sweep of the launched layout: vectors + the value / index streams.
+bool csr_alternates(const DevCsr &A, const KernelConfig &c)
+{
+    if (c.alt_dir == 0) return false;
+    if (c.alt_dir >= 2) return true;
+    size_t bytes = (size_t)A.nrow * 24;
+    switch (csr_family(A, c)) {
+    case FAM_SDIA_TAB: break;
+    case FAM_SDIA: bytes += (size_t)A.sd_vblocks * 64 * 8; break;
+    case FAM_SELL: bytes += (size_t)A.sell_entries * 12; break;
+    case FAM_CSR_ROWLANE16: bytes += (size_t)A.nnz * 10; break;
+    default: bytes += (size_t)A.nnz * 12; break;
+    }
+    return bytes > ((size_t)640 << 20);
+}
+
 // rows per workgroup of the LDS-tiled table kernel for this operator, 0 when it does not apply: grid
 // stencils in lexicographic order (offsets -1, 0, +1 adjacent in the middle of a 5- or 7-entry table) whose
 // +-line reach is small enough for the window [r0 - line, r0 + T + line) to fit 64 KiB of LDS with at most
@@ -1649,6 +1669,27 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int n, const double *
         x[i] = x[i] + alpha * p[i];        // cblas_daxpy(alpha, p, x)
         const double ri = r[i] + nalpha * Ap[i];  // cblas_daxpy(-alpha, Ap, r)
         r[i] = ri;
+        acc += ri * ri;
+    }
+    const double t = block_sum(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// cg_update + the zero-guess sweep of the V-cycle that follows on the new residual: z0 = omega * r / d (what jacobi_zero_kernel
+// computes from r one launch later; same expression, so the same bits) -- r is not read a second time
+__global__ __launch_bounds__(kBlock) void cg_update_zero_kernel(int n, const double *__restrict__ scal, const double *__restrict__ p,
+                                                                 const double *__restrict__ Ap, double *__restrict__ x, double *__restrict__ r,
+                                                                 double *__restrict__ partial, const double *__restrict__ d, double omega,
+                                                                 double *__restrict__ z0)
+{
+    __shared__ double red[kBlock / 64];
+    const double alpha = scal[S_ALPHA], nalpha = scal[S_NALPHA];
+    double acc = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        x[i] = x[i] + alpha * p[i];
+        const double ri = r[i] + nalpha * Ap[i];
+        r[i] = ri;
+        z0[i] = omega * ri / d[i];
         acc += ri * ri;
     }
     const double t = block_sum(acc, red);
@@ -2050,6 +2091,14 @@ void launch_cg_update(int n, const double *scal, const double *p, const double *
     const int g = ew_grid(n);
     *nblk = g;
     hipLaunchKernelGGL(cg_update_kernel, dim3(g), dim3(kBlock), 0, st, n, scal, p, Ap, x, r, partial);
+}
+
+void launch_cg_update_zero(int n, const double *scal, const double *p, const double *Ap, double *x, double *r, double *partial,
+                           int *nblk, const double *d, double omega, double *z0, hipStream_t st)
+{
+    const int g = ew_grid(n);
+    *nblk = g;
+    hipLaunchKernelGGL(cg_update_zero_kernel, dim3(g), dim3(kBlock), 0, st, n, scal, p, Ap, x, r, partial, d, omega, z0);
 }
 
 void launch_p_update(int n, const double *scal, const double *z, double *p, hipStream_t st)

@@ -94,7 +94,8 @@ struct KernelConfig {
     bool table = true;  // use the level-wide stencil table where a level has one
     bool tile = false;  // table levels of grid stencils: stage x tiles in LDS (sdia_tile_kernel) on whole-level launches
     bool const_slots = true;  // layout option read at setup: fold constant diagonals of a slice into one scalar
-    bool alt_dir = true;      // consecutive sweeps of a smoothing leg walk the level in alternating directions (CsrArgs::reverse)
+    int alt_dir = 1;          // consecutive sweeps of a smoothing leg walk the level in alternating directions (CsrArgs::reverse):
+                              // 0 never, 1 where a sweep streams more than 640 MB (2.5x the Infinity Cache), 2 always
     int idx16 = 1;      // layout option read at setup: build the 16-bit delta column form (DevCsr::col16) for 0 no operator,
                         // 1 operators whose default family is the CSR-stream kernel streaming from HBM, 2 every operator
 };
@@ -153,6 +154,8 @@ int build_col16(const int *rowptr, const int *col, const int *rec, int nblk, uns
 // `finest`: launch on the finest level (selects a separately named kernel instance for profilers)
 int launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool finest, hipStream_t st, const KernelConfig &cfg);
 CsrFamily csr_family(const DevCsr &A, const KernelConfig &cfg);
+// whether consecutive sweeps over A alternate their walking direction under cfg (KernelConfig::alt_dir)
+bool csr_alternates(const DevCsr &A, const KernelConfig &cfg);
 const char *csr_family_name(CsrFamily f);
 int sdia_tile_rows(const DevCsr &A, const KernelConfig &cfg);  // rows per workgroup of the LDS-tiled table kernel, 0 = not used
 // placement the launcher picks for A under cfg: non-temporal matrix stream, XCD remap mode
@@ -237,6 +240,9 @@ void launch_unpack(int n, const int *pos, const double *buf, double *vec, hipStr
 // PCG/CG: x += alpha p ; r += (-alpha) Ap ; partial += r_i^2
 void launch_cg_update(int n, const double *scal, const double *p, const double *Ap, double *x, double *r, double *partial,
                       int *nblk, hipStream_t st);
+// the same, and z0 = omega * r / d on the new residual: the zero-guess sweep of the V-cycle that follows (PCG)
+void launch_cg_update_zero(int n, const double *scal, const double *p, const double *Ap, double *x, double *r, double *partial,
+                           int *nblk, const double *d, double omega, double *z0, hipStream_t st);
 // p = 1.0*z + beta*p
 void launch_p_update(int n, const double *scal, const double *z, double *p, hipStream_t st);
 // two dots at once: partial0 += a.b, partial1 += c.d
