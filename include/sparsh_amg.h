@@ -161,6 +161,9 @@ int sparsh_setup_share_info(sparsh_handle h, int *built_locally, long *image_byt
  * truncate_to >= 0) and compares every array of the two hierarchies; returns the image size or a negative SPARSH_E*. */
 long sparsh_debug_hierarchy_roundtrip(sparsh_handle h, long truncate_to);
 int sparsh_level_index16(sparsh_handle h, int level, long *blocks16, long *blocks);
+/* Test hook (host only, no handle): builds the row-block schedule and the 16-bit delta form of a CSR pattern, decodes it again
+ * and compares with colindex; reports how many row blocks took the 16-bit form. */
+int sparsh_debug_index16_roundtrip(int nrow, const int *rowptr, const int *colindex, long *blocks16, long *blocks);
 /* Table levels of grid stencils (offsets -1, 0, +1, +-line[, +-plane]) run, on whole-level launches, a
  * variant that stages x[r0 - line, r0 + T + line) of every workgroup's T rows in LDS, so the centre, +-1 and
  * +-line neighbours come out of LDS and only the +-plane neighbours are gathered from L2 (bitwise the same

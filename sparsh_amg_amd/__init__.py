@@ -89,6 +89,7 @@ def _load():
         "sparsh_set_tile": (C.c_int, [H, C.c_int]),
         "sparsh_set_index_compression": (C.c_int, [H, C.c_int]),
         "sparsh_set_alternate_sweeps": (C.c_int, [H, C.c_int]),
+        "sparsh_debug_index16_roundtrip": (C.c_int, [C.c_int, c_int_p, c_int_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
         "sparsh_set_setup_broadcast": (C.c_int, [H, C.c_int]),
         "sparsh_debug_hierarchy_roundtrip": (C.c_long, [H, C.c_long]),
         "sparsh_setup_share_info": (C.c_int, [H, C.POINTER(C.c_int), C.POINTER(C.c_long)]),
@@ -208,6 +209,16 @@ def comm_group_destroy(g):
 def comm_group_fail_after(g, ncalls: int):
     """Fault injection (tests): every rank's halo exchange number `ncalls` and all later ones fail."""
     _check(lib.sparsh_comm_group_fail_after(g, int(ncalls)))
+
+
+def index16_roundtrip(rowptr, colindex):
+    """Test hook (host only): (row blocks in 16-bit delta form, row blocks) of a CSR pattern; raises if the form does not decode
+    back to colindex."""
+    rp = np.ascontiguousarray(rowptr, dtype=np.int32)
+    ci = np.ascontiguousarray(colindex, dtype=np.int32)
+    a, b = C.c_long(), C.c_long()
+    _check(lib.sparsh_debug_index16_roundtrip(len(rp) - 1, _ip(rp), _ip(ci), C.byref(a), C.byref(b)))
+    return a.value, b.value
 
 
 def device_count() -> int:

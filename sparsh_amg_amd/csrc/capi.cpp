@@ -342,6 +342,33 @@ long sparsh_debug_hierarchy_roundtrip(sparsh_handle h, long truncate_to)
     return (long)img.size();
 }
 
+// test hook (host only): row-block schedule -> 16-bit delta form -> decoded columns, compared with the input
+int sparsh_debug_index16_roundtrip(int nrow, const int *rowptr, const int *col, long *blocks16, long *blocks)
+{
+    if (nrow < 0 || !rowptr || (!col && rowptr[nrow] > 0)) return fail(SPARSH_EINVAL, "bad arguments");
+    int nblk = 0;
+    const std::vector<int> rec = rowblock_records(nrow, rowptr, &nblk);
+    std::vector<unsigned short> c16((size_t)rowptr[nrow] + kCsrPad, 0);
+    std::vector<int> cb((size_t)std::max(nblk, 1), -1);
+    const int n16 = build_col16(rowptr, col, rec.data(), nblk, c16.data(), cb.data());
+    int counted = 0;
+    for (int k = 0; k < nblk; ++k) {
+        if (cb[k] < 0) continue;
+        ++counted;
+        for (int r = rec[(size_t)4 * k]; r < rec[(size_t)4 * k + 1]; ++r) {
+            int c = cb[k];
+            for (int j = rowptr[r]; j < rowptr[r + 1]; ++j) {
+                c += c16[j];
+                if (c != col[j]) return fail(SPARSH_ENUMERIC, "16-bit delta form decodes to a different column");
+            }
+        }
+    }
+    if (counted != n16) return fail(SPARSH_ENUMERIC, "block count mismatch");
+    if (blocks16) *blocks16 = n16;
+    if (blocks) *blocks = nblk;
+    return SPARSH_OK;
+}
+
 int sparsh_set_alternate_sweeps(sparsh_handle h, int enable)
 {
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");

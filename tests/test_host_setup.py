@@ -115,6 +115,32 @@ def test_extended_hierarchy():
     assert A.level_info(A.nlevels - 1)["nrow"] <= 5000
 
 
+def test_index16_encoder_roundtrip():
+    """Host encoder of the 16-bit delta column form (csr_rowlane16_kernel): decodes back to colindex; blocks with a gap of
+    65536 or more, an unsorted row or one over-long row keep their 32-bit indices."""
+    import scipy.sparse as sp
+
+    rp, ci, v = problems.poisson3d(48)            # +-2304 neighbours: every block fits
+    b16, nb = sa.index16_roundtrip(rp, ci)
+    assert b16 == nb > 100
+    rp, ci, v = problems.fem_unstructured(30000, seed=3)
+    b16, nb = sa.index16_roundtrip(rp, ci)
+    assert b16 == nb
+    n = 200000
+    M = sp.diags([np.ones(n - 1), 2 * np.ones(n), np.ones(n - 1)], [-1, 0, 1], format="lil")
+    M[7, 150000] = 1.0                      # gap > 65535 inside a row
+    M[100000, :3000] = 1.0                  # a row longer than the LDS buffer of the kernel
+    M = M.tocsr()
+    M.sort_indices()
+    b16, nb = sa.index16_roundtrip(M.indptr, M.indices)
+    assert 0 < nb - b16 <= 4
+    ci2 = M.indices.copy()
+    s0, s1 = M.indptr[150000], M.indptr[150001]
+    ci2[s0:s1] = ci2[s0:s1][::-1]           # an unsorted row: its block falls back, nothing breaks
+    b16b, nb2 = sa.index16_roundtrip(M.indptr, ci2)
+    assert nb2 == nb and b16b == b16 - 1
+
+
 def test_hierarchy_image_roundtrip():
     """The byte image rank 0 broadcasts in a multi-GPU setup reproduces the hierarchy array by array (HEM: aggregation
     P; Beck: general P / R; dense coarse inverse or none), and a truncated image is refused, not half-read."""
