@@ -148,6 +148,9 @@ int sparsh_set_index_compression(sparsh_handle h, int mode);
  * 640 MB = 2.5x the Infinity Cache (matrix-streaming layouts of large levels: -3...6 % per sweep; smaller levels and the
  * value-free table path measured neutral within +-1 %); 2: always alternate (A/B). */
 int sparsh_set_alternate_sweeps(sparsh_handle h, int mode);
+/* PCG: the x / r update kernel also writes the zero-guess sweep z0 = omega r / d of the V-cycle that follows (same bits, one
+ * read of r and one launch less).  sparsh_set_fused_zero_sweep(h, 0) keeps the separate launch (A/B). */
+int sparsh_set_fused_zero_sweep(sparsh_handle h, int enable);
 /* Multi-GPU setup: by default rank 0 alone runs the host setup (coarsening, Galerkin products, coarse factor) and the other
  * ranks receive the finished hierarchy through the transport (one RCCL broadcast of its byte image, staged through HBM in
  * 256 MB pieces) instead of repeating the identical setup N times; every rank then cuts out and uploads its own row

@@ -89,6 +89,7 @@ def _load():
         "sparsh_set_tile": (C.c_int, [H, C.c_int]),
         "sparsh_set_index_compression": (C.c_int, [H, C.c_int]),
         "sparsh_set_alternate_sweeps": (C.c_int, [H, C.c_int]),
+        "sparsh_set_fused_zero_sweep": (C.c_int, [H, C.c_int]),
         "sparsh_debug_index16_roundtrip": (C.c_int, [C.c_int, c_int_p, c_int_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
         "sparsh_set_setup_broadcast": (C.c_int, [H, C.c_int]),
         "sparsh_debug_hierarchy_roundtrip": (C.c_long, [H, C.c_long]),
@@ -286,6 +287,11 @@ class sp_matrix_mg:
         a, b = C.c_int(), C.c_long()
         _check(lib.sparsh_setup_share_info(self._h, C.byref(a), C.byref(b)))
         return bool(a.value), b.value
+
+    def set_fused_zero_sweep(self, enable=True):
+        """PCG: cg_update also writes the zero-guess sweep of the V-cycle (default on); any time."""
+        _check(lib.sparsh_set_fused_zero_sweep(self._h, int(bool(enable))))
+        return self
 
     def set_alternate_sweeps(self, mode=1):
         """Alternate the walking direction of consecutive sweeps of a smoothing leg: 0 never, 1 large streaming levels (default), 2 always."""

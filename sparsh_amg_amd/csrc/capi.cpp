@@ -369,6 +369,13 @@ int sparsh_debug_index16_roundtrip(int nrow, const int *rowptr, const int *col, 
     return SPARSH_OK;
 }
 
+int sparsh_set_fused_zero_sweep(sparsh_handle h, int enable)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    h->eng->kernel_cfg().fuse_cg_zero = enable != 0;
+    return SPARSH_OK;
+}
+
 int sparsh_set_alternate_sweeps(sparsh_handle h, int enable)
 {
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
