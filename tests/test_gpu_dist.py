@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 QUIET = dict(print_setup=0, print_solve=0)
 
 
-def run_ranks(rp, ci, v, b, G, method, overlap=False, deep=None, **kw):
+def run_ranks(rp, ci, v, b, G, method, overlap=False, deep=None, kcfg=None, idx16=None, **kw):
     group = sa.comm_group_create(G)
     out = [None] * G
     errs = []
@@ -24,6 +24,10 @@ def run_ranks(rp, ci, v, b, G, method, overlap=False, deep=None, **kw):
         try:
             A = sa.sp_matrix_mg(rp, ci, v)
             A.comm_init_group(group, r)
+            if idx16 is not None:
+                A.set_index_compression(idx16)
+            if kcfg is not None:
+                A.set_kernel_config(*kcfg)
             if deep is not None or overlap:
                 A.set_deep_halo(bool(deep) and not overlap)  # the overlapped schedule belongs to the per-sweep exchange path
             A.setup(sa.default_params(**QUIET, **kw))
@@ -97,6 +101,25 @@ def test_virtual_ranks_match_single_rank(name, G):
             tol = np.where(h1 >= 1e-6 * h1[0], 1e-8, 1e-4)
             assert np.all(np.abs(h - h1) <= tol * h1), np.abs(h / h1 - 1).max()
         assert np.linalg.norm(x - x1) <= 1e-8 * np.linalg.norm(x1)
+
+
+@pytest.mark.parametrize("deep", [True, False])
+def test_compressed_indices_on_rank_local_operators(deep):
+    """16-bit delta-coded column indices on the rank-local operators of a partitioned solve (halo columns are numbered after
+    the own ones, so some rows are not ascending locally: their blocks keep 32-bit indices): fixed-cycle solution bitwise equal
+    to the single-rank one, for the deep-halo and the per-sweep exchange schedule."""
+    for gen, kw in ((lambda: problems.poisson3d(30), dict(replicate_rows=2000)),
+                    (lambda: problems.fem_unstructured(40000, seed=5), dict(replicate_rows=3000))):
+        rp, ci, v = gen()
+        n = len(rp) - 1
+        b = np.random.default_rng(4).standard_normal(n)
+        A1 = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET))
+        x1 = np.zeros(n)
+        A1.vcycle(b, x1, iterations=3)
+        A1.close()
+        res = run_ranks(rp, ci, v, b, 3, "vcycle3", deep=deep, kcfg=(0, 4, -1, -1), idx16=2, **kw)
+        x = np.concatenate([r[3] for r in sorted(res, key=lambda t: t[0])])
+        assert np.array_equal(x, x1)
 
 
 def test_hierarchy_broadcast_from_rank0():
