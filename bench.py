@@ -311,6 +311,18 @@ def main():
             "csr_model_frac": round(jac_bytes / avg / 1e9 / HBM_PEAK_GBS, 4),
             "layout": {"slots": slots, "value_blocks": vblocks, "constant_slots": slots - vblocks, "descriptor_bytes": meta_bytes} if fmt == 3 else None,
         }
+        if world == 1 and mode == "single":
+            # the same kernel launched back to back in this process (outside the timed region): the in-solve figure above varies
+            # from process to process with the physical placement of a working set the size of the Infinity Cache
+            try:
+                b2b = A.bench_op("jacobi_pingpong", 0, 20)
+                roof["back_to_back_us"] = round(b2b * 1e6, 2)
+                roof["back_to_back_frac"] = round(fmt_bytes / b2b / 1e9 / HBM_PEAK_GBS, 4)
+                roof["note"] += (". avg_us is measured inside the solve; back_to_back_us is the same kernel ping-ponging between two vectors alone. "
+                                 "For the default table path at 216^3 (0.24 GB working set = the Infinity Cache) the in-solve time varies 48-68 us from "
+                                 "process to process with physical page placement (profiles/r02_finest_sweep_placement_luck.txt)")
+            except Exception as e:  # noqa: BLE001
+                log(f"back-to-back measurement failed: {e!r}")
 
     # whole-iteration algorithmic bytes: V-cycle + SpMV + 2 dot + nrm2 + 3 axpy-type
     it_bytes = vcycle_bytes(levels, sweeps) + (12 * nnz + 20 * n) + 2 * 16 * n + 8 * n + 3 * 24 * n
