@@ -319,8 +319,9 @@ def main():
                 roof["back_to_back_us"] = round(b2b * 1e6, 2)
                 roof["back_to_back_frac"] = round(fmt_bytes / b2b / 1e9 / HBM_PEAK_GBS, 4)
                 roof["note"] += (". avg_us is measured inside the solve; back_to_back_us is the same kernel ping-ponging between two vectors alone. "
-                                 "For the default table path at 216^3 (0.24 GB working set = the Infinity Cache) the in-solve time varies 48-68 us from "
-                                 "process to process with physical page placement (profiles/r02_finest_sweep_placement_luck.txt)")
+                                 "For the default table path at 216^3 the three sweep vectors (0.24 GB) are the size of the Infinity Cache: the same sweep takes 42-64 us "
+                                 "depending on the physical pages behind them, so sparsh_setup picks the buffers by timing (config.placement_search; "
+                                 "profiles/r02_finest_sweep_placement_luck.txt)")
             except Exception as e:  # noqa: BLE001
                 log(f"back-to-back measurement failed: {e!r}")
 
@@ -591,6 +592,7 @@ def main():
                 "hierarchy_setup": (None if mode != "partitioned" else
                                     (lambda bi: f"rank 0 ran the host setup, {bi[1] / 1e6:.0f} MB hierarchy image broadcast to the other ranks (ncclBroadcast)"
                                      if bi[1] > 0 else "every rank ran the host setup itself")(A.setup_share_info())),
+                "placement_search": A.placement_info() if world == 1 else None,  # setup-time choice of the finest level's sweep buffers
                 "multi_gpu_parity": parity,
                 "algorithmic_GB_per_iteration": round(it_bytes / 1e9, 3),
                 "solve_GBps": round(it_bytes * its_per_s / 1e9, 1),

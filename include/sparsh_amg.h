@@ -151,6 +151,16 @@ int sparsh_set_alternate_sweeps(sparsh_handle h, int mode);
 /* PCG: the x / r update kernel also writes the zero-guess sweep z0 = omega r / d of the V-cycle that follows (same bits, one
  * read of r and one launch less).  sparsh_set_fused_zero_sweep(h, 0) keeps the separate launch (A/B). */
 int sparsh_set_fused_zero_sweep(sparsh_handle h, int enable);
+/* Placement search (single GPU, stencil-table levels whose three sweep vectors together are about the size of the 256 MB
+ * Infinity Cache): sparsh_setup times the finest-level sweep on candidate triples among the equally sized buffers the
+ * engine owns anyway (plus five spares, freed again) until one runs cache-resident, at most 260 triples (~0.1 s), and lets
+ * the fastest triple hold iterate / ping-pong twin / Krylov residual -- the same sweep takes 44 to
+ * 63 us depending on the physical pages behind the three vectors.  Pointers only: no extra memory, identical results.
+ * sparsh_set_placement_search(h, 0) before sparsh_setup keeps the allocation order (A/B).  sparsh_placement_info: sweep time
+ * of the chosen, the worst and the initial triple in microseconds, the number of triples timed (0: search not run) and the
+ * seconds the search took. */
+int sparsh_set_placement_search(sparsh_handle h, int enable);
+int sparsh_placement_info(sparsh_handle h, double *chosen_us, double *worst_us, double *initial_us, int *triples, double *seconds);
 /* Multi-GPU setup: by default rank 0 alone runs the host setup (coarsening, Galerkin products, coarse factor) and the other
  * ranks receive the finished hierarchy through the transport (one RCCL broadcast of its byte image, staged through HBM in
  * 256 MB pieces) instead of repeating the identical setup N times; every rank then cuts out and uploads its own row

@@ -90,6 +90,8 @@ def _load():
         "sparsh_set_index_compression": (C.c_int, [H, C.c_int]),
         "sparsh_set_alternate_sweeps": (C.c_int, [H, C.c_int]),
         "sparsh_set_fused_zero_sweep": (C.c_int, [H, C.c_int]),
+        "sparsh_set_placement_search": (C.c_int, [H, C.c_int]),
+        "sparsh_placement_info": (C.c_int, [H, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), c_int_p, C.POINTER(C.c_double)]),
         "sparsh_debug_index16_roundtrip": (C.c_int, [C.c_int, c_int_p, c_int_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
         "sparsh_set_setup_broadcast": (C.c_int, [H, C.c_int]),
         "sparsh_debug_hierarchy_roundtrip": (C.c_long, [H, C.c_long]),
@@ -287,6 +289,18 @@ class sp_matrix_mg:
         a, b = C.c_int(), C.c_long()
         _check(lib.sparsh_setup_share_info(self._h, C.byref(a), C.byref(b)))
         return bool(a.value), b.value
+
+    def set_placement_search(self, enable=True):
+        """Setup-time choice of the buffers that hold the finest level's sweep vectors (default on); before setup."""
+        _check(lib.sparsh_set_placement_search(self._h, int(bool(enable))))
+        return self
+
+    def placement_info(self):
+        """Sweep time (us) of the chosen / worst / initial buffer triple and the number of triples timed at setup."""
+        a, b, c, k, t = C.c_double(), C.c_double(), C.c_double(), C.c_int(), C.c_double()
+        _check(lib.sparsh_placement_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(k), C.byref(t)))
+        return {"chosen_us": round(a.value, 2), "worst_us": round(b.value, 2), "initial_us": round(c.value, 2), "triples": k.value,
+                "seconds": round(t.value, 3)}
 
     def set_fused_zero_sweep(self, enable=True):
         """PCG: cg_update also writes the zero-guess sweep of the V-cycle (default on); any time."""

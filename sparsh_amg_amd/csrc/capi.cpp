@@ -369,6 +369,24 @@ int sparsh_debug_index16_roundtrip(int nrow, const int *rowptr, const int *col, 
     return SPARSH_OK;
 }
 
+int sparsh_set_placement_search(sparsh_handle h, int enable)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    h->eng->kernel_cfg().place_search = enable != 0;
+    return SPARSH_OK;
+}
+
+int sparsh_placement_info(sparsh_handle h, double *chosen_us, double *worst_us, double *initial_us, int *triples, double *seconds)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    if (chosen_us) *chosen_us = h->eng->place_best_us;
+    if (worst_us) *worst_us = h->eng->place_worst_us;
+    if (initial_us) *initial_us = h->eng->place_first_us;
+    if (triples) *triples = h->eng->place_tried;
+    if (seconds) *seconds = h->eng->place_seconds;
+    return SPARSH_OK;
+}
+
 int sparsh_set_fused_zero_sweep(sparsh_handle h, int enable)
 {
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");

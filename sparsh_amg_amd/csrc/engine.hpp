@@ -167,6 +167,10 @@ public:
     void profile_begin();    // (re)arm the event pool
     void profile_collect();  // sync and sum the recorded launch times
     double setup_seconds = 0.0;
+    // placement search of the last setup: sweep time of the chosen / the worst / the initial triple (us), triples tried (0: not run)
+    double place_best_us = 0.0, place_worst_us = 0.0, place_first_us = 0.0;
+    int place_tried = 0;
+    double place_seconds = 0.0;
 
 private:
     // one V(nu,nu) cycle: rhs b0 (device, read-only), solution accumulates in lev_[0].x.
@@ -240,6 +244,9 @@ private:
     double *pinned_ = nullptr;    // host-pinned staging for scalar read-back
     std::vector<double *> work_;  // level-0 work vectors of the Krylov loops
     std::vector<void *> allocs_;
+    // which of the finest level's equally sized buffers play iterate / ping-pong twin / Krylov residual: chosen at setup by
+    // timing the sweep on the candidates (see tune_placement)
+    void tune_placement();
 };
 
 }  // namespace sparsh

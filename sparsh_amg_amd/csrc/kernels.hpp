@@ -94,6 +94,7 @@ struct KernelConfig {
     bool table = true;  // use the level-wide stencil table where a level has one
     bool tile = false;  // table levels of grid stencils: stage x tiles in LDS (sdia_tile_kernel) on whole-level launches
     bool const_slots = true;  // layout option read at setup: fold constant diagonals of a slice into one scalar
+    bool place_search = true; // setup: choose by timing which buffers hold the finest level's iterate, its twin and the Krylov residual
     bool fuse_cg_zero = true; // PCG: the cg_update kernel also writes the V-cycle's zero-guess sweep of level 0
     int alt_dir = 1;          // consecutive sweeps of a smoothing leg walk the level in alternating directions (CsrArgs::reverse):
                               // 0 never, 1 where a sweep streams more than 640 MB (2.5x the Infinity Cache), 2 always
