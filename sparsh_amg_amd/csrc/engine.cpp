@@ -1368,6 +1368,12 @@ int Engine::amg_solve_dev(const double *b, double *x, int iterations, double *hi
     DevLevel &L0 = lev_[0];
     const int n = L0.n;
     HIPCHK(hipMemcpyAsync(L0.x, x, (size_t)n * 8, hipMemcpyDeviceToDevice, st_));
+    if (place_tried > 0 && !dist_ && !L0.deep && !ks_.active) {  // (an open Krylov session owns work_[0])
+        // the setup chose the buffers of iterate, twin and right-hand side together (tune_placement): run the cycles on the
+        // engine's copy of b instead of on a caller buffer placed wherever it happens to be (one 8n-byte copy per solve)
+        HIPCHK(hipMemcpyAsync(work_[0], b, (size_t)n * 8, hipMemcpyDeviceToDevice, st_));
+        b = work_[0];
+    }
     int cycles = 0;
     double r1 = op_resnorm(0, b, L0.x);
     int rc = SPARSH_OK;
