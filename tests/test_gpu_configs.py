@@ -471,3 +471,28 @@ def test_config4_full_size_breakdown_like_the_oracle(config4_full):
     # |x| ~ 530 here (mass-dominated rows, b = 1e-3): the true residual sits a few 1e-8 above the recurrence's
     # (||A|| ||x|| eps drift); the stopping rule is the reference's, on the recurrence
     assert hp[-1] <= 1e-8 and np.linalg.norm(b - S @ x) <= 1e-7
+
+
+def test_placement_search_changes_nothing_but_pointers():
+    """Setup-time placement search (Engine::tune_placement): on a level whose three sweep vectors are about the size of the
+    Infinity Cache the engine picks, by timing, which of its buffers hold iterate / twin / Krylov residual.  Pointers only:
+    residual histories and solutions are bit for bit those of a handle that keeps the allocation order."""
+    rp, ci, v = problems.poisson3d(168)  # 4.7 M rows: 114 MB of sweep vectors, just above the smallest size the search looks at (96 MiB)
+    n = len(rp) - 1
+    b = np.ones(n)
+    res = []
+    for search in (True, False):
+        A = sa.sp_matrix_mg(rp, ci, v).set_placement_search(search).setup(sa.default_params(**QUIET))
+        info = A.placement_info()
+        if search:
+            assert 0 < info["triples"] <= 260 and 0 < info["chosen_us"] <= info["initial_us"] <= info["worst_us"], info
+        else:
+            assert info["triples"] == 0
+        x = np.zeros(n)
+        h, rc = A.solve("pcg", b, x)
+        xa = np.zeros(n)
+        ha, rca = A.solve("amg", b, xa)
+        res.append((h, rc, x, ha, rca, xa))
+        A.close()
+    for u, w in zip(res[0], res[1]):
+        assert np.array_equal(u, w)
