@@ -149,8 +149,10 @@ int sparsh_set_index_compression(sparsh_handle h, int mode);
  * value-free table path measured neutral within +-1 %); 2: always alternate (A/B). */
 int sparsh_set_alternate_sweeps(sparsh_handle h, int mode);
 /* PCG: the x / r update kernel also writes the zero-guess sweep z0 = omega r / d of the V-cycle that follows (same bits, one
- * read of r and one launch less).  sparsh_set_fused_zero_sweep(h, 0) keeps the separate launch (A/B). */
-int sparsh_set_fused_zero_sweep(sparsh_handle h, int enable);
+ * read of r and one launch less), and streams x, p, Ap and d past the caches (non-temporal loads / stores) so that r and z0,
+ * which the cycle's first sweep reads next, are what stays resident.  mode 2 (default): both; 1: fused, ordinary loads;
+ * 0: separate launch (A/B). */
+int sparsh_set_fused_zero_sweep(sparsh_handle h, int mode);
 /* Placement search (single GPU, stencil-table levels whose three sweep vectors together are about the size of the 256 MB
  * Infinity Cache): sparsh_setup times the finest-level sweep on candidate triples among the equally sized buffers the
  * engine owns anyway (plus five spares, freed again) until one runs cache-resident, at most 260 triples (~0.1 s), and lets

@@ -302,9 +302,9 @@ class sp_matrix_mg:
         return {"chosen_us": round(a.value, 2), "worst_us": round(b.value, 2), "initial_us": round(c.value, 2), "triples": k.value,
                 "seconds": round(t.value, 3)}
 
-    def set_fused_zero_sweep(self, enable=True):
-        """PCG: cg_update also writes the zero-guess sweep of the V-cycle (default on); any time."""
-        _check(lib.sparsh_set_fused_zero_sweep(self._h, int(bool(enable))))
+    def set_fused_zero_sweep(self, enable=2):
+        """PCG: cg_update also writes the zero-guess sweep of the V-cycle: 0 off, 1 fused, 2 fused + non-temporal streams (default)."""
+        _check(lib.sparsh_set_fused_zero_sweep(self._h, int(enable)))
         return self
 
     def set_alternate_sweeps(self, mode=1):

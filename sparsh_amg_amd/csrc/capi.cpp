@@ -391,6 +391,7 @@ int sparsh_set_fused_zero_sweep(sparsh_handle h, int enable)
 {
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
     h->eng->kernel_cfg().fuse_cg_zero = enable != 0;
+    h->eng->kernel_cfg().cg_nt = enable == 2;
     return SPARSH_OK;
 }
 

@@ -1462,7 +1462,7 @@ void Engine::pcg_body(bool precond, int slot)
     // with the fp64 V-cycle behind it the update also writes the cycle's zero-guess sweep of level 0 (z0 = omega r / d)
     const bool fuse_zero = cfg_.fuse_cg_zero && precond && !f32_ready_ && lev_.size() > 1 && !lev_[0].deep && prm_.sweeps > 0;
     if (fuse_zero)
-        launch_cg_update_zero(n, scal_, p, Ap, x, r, part1_, &nb, lev_[0].diag, prm_.omega, lev_[0].x, st_);
+        launch_cg_update_zero(n, scal_, p, Ap, x, r, part1_, &nb, lev_[0].diag, prm_.omega, lev_[0].x, st_, cfg_.cg_nt);
     else
         launch_cg_update(n, scal_, p, Ap, x, r, precond ? part1_ : part0_, &nb, st_);
     if (precond && f32_ready_) {

@@ -1677,6 +1677,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int n, const double *
 
 // cg_update + the zero-guess sweep of the V-cycle that follows on the new residual: z0 = omega * r / d (what jacobi_zero_kernel
 // computes from r one launch later; same expression, so the same bits) -- r is not read a second time
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void cg_update_zero_kernel(int n, const double *__restrict__ scal, const double *__restrict__ p,
                                                                  const double *__restrict__ Ap, double *__restrict__ x, double *__restrict__ r,
                                                                  double *__restrict__ partial, const double *__restrict__ d, double omega,
@@ -1686,10 +1687,18 @@ __global__ __launch_bounds__(kBlock) void cg_update_zero_kernel(int n, const dou
     const double alpha = scal[S_ALPHA], nalpha = scal[S_NALPHA];
     double acc = 0.0;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        x[i] = x[i] + alpha * p[i];
-        const double ri = r[i] + nalpha * Ap[i];
+        // NT: x, p, Ap and d are not touched again before the cycle is over -- streamed past the caches, so that r and z0, which the
+        // first sweep of the cycle reads next, are what stays resident
+        const double xi = NT ? __builtin_nontemporal_load(x + i) : x[i];
+        const double pi = NT ? __builtin_nontemporal_load(p + i) : p[i];
+        const double api = NT ? __builtin_nontemporal_load(Ap + i) : Ap[i];
+        const double di = NT ? __builtin_nontemporal_load(d + i) : d[i];
+        const double xn = xi + alpha * pi;
+        if (NT) __builtin_nontemporal_store(xn, x + i);
+        else x[i] = xn;
+        const double ri = r[i] + nalpha * api;
         r[i] = ri;
-        z0[i] = omega * ri / d[i];
+        z0[i] = omega * ri / di;
         acc += ri * ri;
     }
     const double t = block_sum(acc, red);
@@ -2094,11 +2103,14 @@ void launch_cg_update(int n, const double *scal, const double *p, const double *
 }
 
 void launch_cg_update_zero(int n, const double *scal, const double *p, const double *Ap, double *x, double *r, double *partial,
-                           int *nblk, const double *d, double omega, double *z0, hipStream_t st)
+                           int *nblk, const double *d, double omega, double *z0, hipStream_t st, bool nt)
 {
     const int g = ew_grid(n);
     *nblk = g;
-    hipLaunchKernelGGL(cg_update_zero_kernel, dim3(g), dim3(kBlock), 0, st, n, scal, p, Ap, x, r, partial, d, omega, z0);
+    if (nt)
+        hipLaunchKernelGGL(cg_update_zero_kernel<true>, dim3(g), dim3(kBlock), 0, st, n, scal, p, Ap, x, r, partial, d, omega, z0);
+    else
+        hipLaunchKernelGGL(cg_update_zero_kernel<false>, dim3(g), dim3(kBlock), 0, st, n, scal, p, Ap, x, r, partial, d, omega, z0);
 }
 
 void launch_p_update(int n, const double *scal, const double *z, double *p, hipStream_t st)

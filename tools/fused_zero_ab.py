@@ -16,8 +16,8 @@ A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, print_solv
 bd, xd = A.dev_alloc(8 * N), A.dev_alloc(8 * N)
 A.h2d(bd, np.ones(N))
 for rnd in range(4):
-    for fz in (0, 1):
-        A.set_fused_zero_sweep(bool(fz))
+    for fz in (0, 1, 2):  # 2: fused, with x / p / Ap / d streamed non-temporally
+        A.set_fused_zero_sweep(fz)
         best = 0.0
         for rep in range(2):
             A.h2d(xd, np.zeros(N))
