@@ -218,7 +218,8 @@ __global__ __launch_bounds__(kCB) void bt_solve_kernel(BtStep s, int mode, int f
                                                        const double *__restrict__ sinv, const int *__restrict__ perm,
                                                        const int *__restrict__ a_rp, const int *__restrict__ a_ci,
                                                        const double *__restrict__ a_v, int ell_k, int n,
-                                                       const int *__restrict__ e_ci, const double *__restrict__ e_v,
+                                                       const int *__restrict__ e_ci, const double *__restrict__ e_v, int e_over,
+                                                       const int *__restrict__ o_rp, const int *__restrict__ o_ci, const double *__restrict__ o_v,
                                                        const double *__restrict__ b, double *__restrict__ z, double *__restrict__ x)
 {
     extern __shared__ double w[];
@@ -248,19 +249,41 @@ __global__ __launch_bounds__(kCB) void bt_solve_kernel(BtStep s, int mode, int f
     };
     load_chunk(0);
     if (ell_k > 0) {
-        // ELL form of the coupling piece (entry k of row g at [k*n + g]; padding: value 0 on the row's own
-        // index): index/value loads do not wait for a row pointer, so the chain in front of w is two loads deep
-        for (int r = threadIdx.x; r < bs; r += kCB) {
-            const int g = r0 + r;
-            const double bg = mode == 0 ? b[perm[g]] : 0.0;
-            double acc = 0.0;
-#pragma unroll 4
-            for (int k = 0; k < ell_k; ++k) {
-                const double ev = e_v[(size_t)k * n + g];
-                const double zv = z[e_ci[(size_t)k * n + g]];
-                acc += ev != 0.0 ? ev * zv : 0.0;  // padding must not pick up a NaN a broken-down solve left in z
+        // ELL form of the coupling piece (entry k of row g at [k*n + g], at most 8 per row; padding: value 0 on the row's own
+        // index, so every gather is a valid access).  A thread owns up to 4 rows per pass (r, r + 256, ...) and issues the index /
+        // value loads of all of them, then all z gathers, then the sums: two dependent loads deep for the whole block instead of
+        // two per row -- 100^3: 357 -> 268 us per solve.  (Gathers must stay unconditional: predicated ones serialise and made the
+        // same idea 25 % slower.)  Rows with more than 8 entries continue, in row order, through the overflow CSR.
+        constexpr int RB = 4, KMAX = 8;
+        for (int rb = threadIdx.x; rb < bs; rb += RB * kCB) {
+            int ci[RB][KMAX], g[RB];
+            double ev[RB][KMAX], zv[RB][KMAX], bg[RB];
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                const int r = rb + q * kCB;
+                g[q] = r0 + (r < bs ? r : 0);
+                bg[q] = mode == 0 ? b[perm[g[q]]] : 0.0;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    const int kk = k < ell_k ? k : 0;
+                    ci[q][k] = e_ci[(size_t)kk * n + g[q]];
+                    ev[q][k] = k < ell_k ? e_v[(size_t)kk * n + g[q]] : 0.0;
+                }
             }
-            w[r] = mode == 0 ? bg - acc : acc;
+#pragma unroll
+            for (int q = 0; q < RB; ++q)
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) zv[q][k] = z[ci[q][k]];
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                const int r = rb + q * kCB;
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) acc += ev[q][k] != 0.0 ? ev[q][k] * zv[q][k] : 0.0;  // padding must not pick up a NaN left in z
+                if (e_over && r < bs)
+                    for (int j = o_rp[g[q]]; j < o_rp[g[q] + 1]; ++j) acc += o_v[j] * z[o_ci[j]];
+                if (r < bs) w[r] = mode == 0 ? bg[q] - acc : acc;
+            }
         }
     } else {
         for (int r = threadIdx.x; r < bs; r += kCB) {
@@ -647,7 +670,7 @@ void bt_launch_solve_step(const int r0[2], const int bs[2], const int blk[2], in
     s.nblk = nblk;
     const int gx = (mx + kSolveRows - 1) / kSolveRows;
     hipLaunchKernelGGL(bt_solve_kernel, dim3(gx, nblk), dim3(kCB), (size_t)mx * sizeof(double), st, s, mode, final_, ld, blk_stride, sinv, perm,
-                       A.rp, A.ci, A.v, E.k, n, E.ci, E.v, b, z, x);
+                       A.rp, A.ci, A.v, E.k, n, E.ci, E.v, E.over, E.orp, E.oci, E.ov, b, z, x);
 }
 
 void bt_launch_winprod(int r0, int bs, int ld, const double *Sinv, const BtDevCsr &XT, int win0, int wn, int ldw, double *out, hipStream_t st)
