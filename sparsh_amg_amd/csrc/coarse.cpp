@@ -132,45 +132,28 @@ T *dev_upload(std::vector<void *> &allocs, const T *src, size_t count, std::stri
     return d;
 }
 
-// ELL copy of a coupling piece for the solve kernel: the first 8 entries of every row, the rest in an overflow CSR
+// ELL copy of a coupling piece for the solve kernel (at most 8 entries per row, else the CSR form is used)
 bool upload_ell(std::vector<void *> &allocs, const HostCsr &M, BtDevEll &E, std::string &err)
 {
     const int n = M.nrow;
-    constexpr int kEllMax = 8;
-    int kmax = 0;
-    for (int i = 0; i < n; ++i) kmax = std::max(kmax, M.rowptr[i + 1] - M.rowptr[i]);
+    int k = 0;
+    for (int i = 0; i < n; ++i) k = std::max(k, M.rowptr[i + 1] - M.rowptr[i]);
     E = BtDevEll();
-    if (kmax == 0) return true;
-    const int k = std::min(kmax, kEllMax);
+    if (k == 0 || k > 8) return true;
     std::vector<int> ci((size_t)k * n);
     std::vector<double> v((size_t)k * n, 0.0);
-    std::vector<int> orp((size_t)n + 1, 0), oci;
-    std::vector<double> ov;
     for (int i = 0; i < n; ++i) {
         int q = 0;
         for (int j = M.rowptr[i]; j < M.rowptr[i + 1]; ++j, ++q) {
-            if (q < k) {
-                ci[(size_t)q * n + i] = M.col[j];
-                v[(size_t)q * n + i] = M.val[j];
-            } else {
-                oci.push_back(M.col[j]);
-                ov.push_back(M.val[j]);
-            }
+            ci[(size_t)q * n + i] = M.col[j];
+            v[(size_t)q * n + i] = M.val[j];
         }
         for (; q < k; ++q) ci[(size_t)q * n + i] = i;
-        orp[(size_t)i + 1] = (int)oci.size();
     }
     E.ci = dev_upload(allocs, ci.data(), ci.size(), err);
     E.v = dev_upload(allocs, v.data(), v.size(), err);
     if (!E.ci || !E.v) return false;
     E.k = k;
-    if (!oci.empty()) {
-        E.orp = dev_upload(allocs, orp.data(), orp.size(), err);
-        E.oci = dev_upload(allocs, oci.data(), oci.size(), err);
-        E.ov = dev_upload(allocs, ov.data(), ov.size(), err);
-        if (!E.orp || !E.oci || !E.ov) return false;
-        E.over = 1;
-    }
     return true;
 }
 

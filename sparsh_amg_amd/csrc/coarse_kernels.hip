@@ -218,8 +218,7 @@ __global__ __launch_bounds__(kCB) void bt_solve_kernel(BtStep s, int mode, int f
                                                        const double *__restrict__ sinv, const int *__restrict__ perm,
                                                        const int *__restrict__ a_rp, const int *__restrict__ a_ci,
                                                        const double *__restrict__ a_v, int ell_k, int n,
-                                                       const int *__restrict__ e_ci, const double *__restrict__ e_v, int e_over,
-                                                       const int *__restrict__ o_rp, const int *__restrict__ o_ci, const double *__restrict__ o_v,
+                                                       const int *__restrict__ e_ci, const double *__restrict__ e_v,
                                                        const double *__restrict__ b, double *__restrict__ z, double *__restrict__ x)
 {
     extern __shared__ double w[];
@@ -253,7 +252,7 @@ __global__ __launch_bounds__(kCB) void bt_solve_kernel(BtStep s, int mode, int f
         // index, so every gather is a valid access).  A thread owns up to 4 rows per pass (r, r + 256, ...) and issues the index /
         // value loads of all of them, then all z gathers, then the sums: two dependent loads deep for the whole block instead of
         // two per row -- 100^3: 357 -> 268 us per solve.  (Gathers must stay unconditional: predicated ones serialise and made the
-        // same idea 25 % slower.)  Rows with more than 8 entries continue, in row order, through the overflow CSR.
+        // same idea 25 % slower.)
         constexpr int RB = 4, KMAX = 8;
         for (int rb = threadIdx.x; rb < bs; rb += RB * kCB) {
             int ci[RB][KMAX], g[RB];
@@ -280,8 +279,6 @@ __global__ __launch_bounds__(kCB) void bt_solve_kernel(BtStep s, int mode, int f
                 double acc = 0.0;
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k) acc += ev[q][k] != 0.0 ? ev[q][k] * zv[q][k] : 0.0;  // padding must not pick up a NaN left in z
-                if (e_over && r < bs)
-                    for (int j = o_rp[g[q]]; j < o_rp[g[q] + 1]; ++j) acc += o_v[j] * z[o_ci[j]];
                 if (r < bs) w[r] = mode == 0 ? bg[q] - acc : acc;
             }
         }
@@ -670,7 +667,7 @@ void bt_launch_solve_step(const int r0[2], const int bs[2], const int blk[2], in
     s.nblk = nblk;
     const int gx = (mx + kSolveRows - 1) / kSolveRows;
     hipLaunchKernelGGL(bt_solve_kernel, dim3(gx, nblk), dim3(kCB), (size_t)mx * sizeof(double), st, s, mode, final_, ld, blk_stride, sinv, perm,
-                       A.rp, A.ci, A.v, E.k, n, E.ci, E.v, E.over, E.orp, E.oci, E.ov, b, z, x);
+                       A.rp, A.ci, A.v, E.k, n, E.ci, E.v, b, z, x);
 }
 
 void bt_launch_winprod(int r0, int bs, int ld, const double *Sinv, const BtDevCsr &XT, int win0, int wn, int ldw, double *out, hipStream_t st)
