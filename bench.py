@@ -151,7 +151,8 @@ def main():
     host_threads = max(1, sa.host_cpus() // max(1, local_world))
     prm = sa.default_params(print_setup=0, print_solve=0, tol=0.0, device=local_rank, check_every=1 << 30, host_threads=host_threads)
     main_cfg = [int(t) for t in kcfg.split(",")] if kcfg else None
-    A = new_handle(fold=not no_fold, cfg=main_cfg)
+    main_idx16 = int(os.environ["SPARSH_BENCH_IDX16"]) if "SPARSH_BENCH_IDX16" in os.environ else None  # profiling runs of the 16-bit index family
+    A = new_handle(fold=not no_fold, cfg=main_cfg, idx16=main_idx16)
     mode, mode_note = "single", None
     if world > 1 or args.rccl:
         # one process per GPU: row-block partition, halo exchange over RCCL.  The 128-byte RCCL id

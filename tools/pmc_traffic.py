@@ -25,7 +25,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 N_GRID = 216
 
 
-def run(grid=N_GRID, cfg=None, no_fold=False, layout_out=None, fem=0):
+def run(grid=N_GRID, cfg=None, no_fold=False, layout_out=None, fem=0, idx16=None, iters=0, coarse_limit=8192):
+    import numpy as np
+
     import sparsh_amg_amd as sa
     from sparsh_amg_amd import problems
 
@@ -33,23 +35,45 @@ def run(grid=N_GRID, cfg=None, no_fold=False, layout_out=None, fem=0):
     A = sa.sp_matrix_mg(rp, ci, v)
     if no_fold:
         A.set_const_slots(False)
+    if idx16 is not None:
+        A.set_index_compression(idx16)
     # coarse_limit = 8192: keep the coarsest level on the dense-inverse path here; the block-tridiagonal
     # factorisation issues tens of thousands of small launches, which the counter-collection mode of the
     # profiler does not survive (segfault inside rocprofv3); the finest-level kernels measured are unaffected
-    A.setup(sa.default_params(print_setup=0, print_solve=0, coarse_limit=8192))
+    A.setup(sa.default_params(print_setup=0, print_solve=0, coarse_limit=coarse_limit))
     cfg = cfg or os.environ.get("SPARSH_PMC_CFG")  # "kind,vec,nt,remap": override the per-operator policy (diagnostics)
     if cfg:
         A.set_kernel_config(*[int(t) for t in cfg.split(",")])
     for op in ("axpby", "dot", "copy_int", "jacobi"):
         A.bench_op(op, 0, 4)
+    if iters > 0:
+        # whole AMG-PCG iterations between marker launches (SURVEY 8d metric (ii): HBM bytes of the whole V-cycle + Krylov
+        # step): the markers are single launches of `copy_int` (used by nothing in the solver; identical to the calibration
+        # launches above, so the calibration average is unaffected): marker, warm-up, marker, K steps, marker
+        n = len(rp) - 1
+        bd = A.dev_alloc(8 * n)
+        xd = A.dev_alloc(8 * n)
+        A.h2d(bd, np.ones(n))
+        A.h2d(xd, np.zeros(n))
+        A.set_stopping(0.0, 100000, 1 << 30)
+        A.bench_op("copy_int", 0, 1)
+        A.krylov_init_dev("pcg", bd, xd)
+        A.krylov_step_dev(2)
+        A.sync()
+        A.bench_op("copy_int", 0, 1)
+        A.krylov_step_dev(iters)
+        A.sync()
+        A.bench_op("copy_int", 0, 1)
     slots, vblocks, meta = A.level_layout(0)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if layout_out is None:
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
         layout_out = os.path.join(root, "gpurun_out", "pmc_layout.json")
     with open(layout_out, "w") as f:
+        b16, nblk = A.level_index16(0)
         json.dump({"slots": slots, "value_blocks": vblocks, "descriptor_bytes": meta, "kernel": A.level_kernel(0), "grid": grid,
-                   "nrow": len(rp) - 1, "nnz": int(rp[-1]), "stored_entries": A.level_format(0)[1]}, f)
+                   "nrow": len(rp) - 1, "nnz": int(rp[-1]), "stored_entries": A.level_format(0)[1], "iters": iters,
+                   "index16_blocks": b16, "row_blocks": nblk}, f)
 
 
 def collect(d):
@@ -65,12 +89,39 @@ def collect(d):
         elif "copy_int_kernel" in name:
             key = "copy_int"
         elif ("sdia_kernel<2" in name or "sdia_tab_kernel<2" in name or "sdia_ord_kernel<2" in name or "sell_kernel<2" in name
-              or "csr_block_kernel<2" in name) and ", 1>" in name:
+              or "csr_block_kernel<2" in name or "csr_rowlane_kernel<2" in name or "csr_rowlane16_kernel<2" in name) and ", 1>" in name:
             key = "jacobi"
-            out["_kind"] = [3.0 if "sdia_" in name else (2.0 if "sell_kernel" in name else 0.0)]
+            out["_kind"] = [3.0 if "sdia_" in name else (2.0 if "sell_kernel" in name else (1.0 if "rowlane16" in name else 0.0))]
         if key:
             out.setdefault(key, []).append(float(r["Counter_Value"]) * 1024.0)
     return {k: sum(v) / len(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
+
+
+def collect_iterations(d):
+    """Sum of the counter over every dispatch between the last two `copy_int` marker launches of run(iters=K)."""
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
+    marks = [i for i, r in enumerate(rows) if "copy_int_kernel" in r["Kernel_Name"]]
+    # a marker is one bench_op call = a run of consecutive copy_int launches (3 warm-up + reps): group them
+    groups = []
+    for i in marks:
+        if groups and i == groups[-1][1] + 1:
+            groups[-1][1] = i
+        else:
+            groups.append([i, i])
+    if len(groups) < 3:
+        return None
+    a, b = groups[-2][1], groups[-1][0]
+    total = 0.0
+    by_kernel = {}
+    for r in rows[a + 1:b]:
+        val = float(r["Counter_Value"]) * 1024.0
+        total += val
+        k = r["Kernel_Name"].split("(")[0]
+        e = by_kernel.setdefault(k, [0, 0.0])
+        e[0] += 1
+        e[1] += val
+    return total, b - a - 1, by_kernel
 
 
 def summarize(fetch_dir, write_dir, out_path, grid=N_GRID, layout_path=None, quiet=False):
@@ -104,7 +155,8 @@ def summarize(fetch_dir, write_dir, out_path, grid=N_GRID, layout_path=None, qui
         pad_nnz = layout.get("stored_entries", nnz)
     kind = int(fetch.pop("_kind", 2.0))
     cnt.pop("_kind", None)
-    bytes4 = (4 * pad_nnz + 4 * n) if kind == 2 else ((4 * nnz + 4 * n) if kind == 0 else 0)
+    # 4-byte-per-lane streams: column indices (+ rowptr); the 16-bit delta form reads one 4-byte word per entry PAIR
+    bytes4 = (4 * pad_nnz + 4 * n) if kind == 2 else ((4 * nnz + 4 * n) if kind == 0 else ((2 * nnz + 4 * n) if kind == 1 else 0))
     bytes8 = (fetch["jacobi"] - bytes4 / f4) * f8
     read_total = bytes4 + bytes8
     # bytes of the value stream: sliced diagonals store 64-value blocks only for non-constant slots
@@ -125,10 +177,25 @@ def summarize(fetch_dir, write_dir, out_path, grid=N_GRID, layout_path=None, qui
         "jacobi_fine_bytes_per_launch": read_total + write["jacobi"] * wf8,
         "jacobi_fine_algorithmic_bytes": alg,
         "ratio_traffic_over_algorithmic": (read_total + write["jacobi"] * wf8) / alg,
-        "kernel_family": {3: "sdia_kernel (sliced diagonals)", 2: "sell_kernel (sliced ELL)", 0: "csr_block_kernel"}.get(kind),
+        "kernel_family": {3: "sdia_kernel (sliced diagonals)", 2: "sell_kernel (sliced ELL)", 0: "CSR-stream (csr_block_kernel / csr_rowlane_kernel)",
+                          1: "CSR-stream, 16-bit delta column indices (csr_rowlane16_kernel)"}.get(kind),
         "layout": layout,
         "x_vector_fetches_per_entry": (bytes8 - val_bytes - meta_bytes - 8 * n) / (8 * n),
     }
+    if layout and layout.get("iters"):
+        K = layout["iters"]
+        fi = collect_iterations(fetch_dir)
+        wi = collect_iterations(write_dir)
+        if fi and wi:
+            # every load stream of these kernels is 4- or 8-byte-per-lane (both calibrated, both x2 within 0.1 %): the 8-byte factor is applied to the sum
+            rd = fi[0] * f8 / K
+            wr = wi[0] * wf8 / K
+            res["iteration"] = {
+                "iterations_measured": K, "dispatches_per_iteration": fi[1] / K,
+                "hbm_read_bytes_per_iteration": rd, "hbm_write_bytes_per_iteration": wr, "hbm_bytes_per_iteration": rd + wr,
+                "top_kernels_by_read_bytes": {k: {"launches_per_iteration": v[0] / K, "read_bytes_per_iteration": v[1] * f8 / K}
+                                              for k, v in sorted(fi[2].items(), key=lambda kv: -kv[1][1])[:8]},
+            }
     if out_path:
         with open(out_path, "w") as f:
             json.dump(res, f, indent=1)
@@ -147,8 +214,11 @@ if __name__ == "__main__":
     ap.add_argument("--no-fold", action="store_true")
     ap.add_argument("--layout", default=None, help="where --run writes / --summarize reads the layout description")
     ap.add_argument("--fem", type=int, default=0, help="--run on the unstructured P1-FEM stand-in with this many points instead of the grid")
+    ap.add_argument("--idx16", type=int, default=None, help="--run: sparsh_set_index_compression mode (2 = every operator)")
+    ap.add_argument("--iters", type=int, default=0, help="--run: also K whole AMG-PCG iterations between marker launches (bytes per iteration)")
+    ap.add_argument("--coarse-limit", type=int, default=8192, help="--run: sparsh_params.coarse_limit (default keeps the coarsest level dense)")
     a = ap.parse_args()
     if a.run:
-        run(a.grid, a.kcfg, a.no_fold, a.layout, a.fem)
+        run(a.grid, a.kcfg, a.no_fold, a.layout, a.fem, a.idx16, a.iters, a.coarse_limit)
     elif a.summarize:
         summarize(a.summarize[0], a.summarize[1], a.out, a.grid, a.layout)
