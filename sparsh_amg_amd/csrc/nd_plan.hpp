@@ -1,0 +1,76 @@
+// nd_plan.hpp -- host plan of the nested-dissection multifrontal direct solver for large coarsest levels
+// (stands where the reference calls PARDISO: analyse + factor once, src/AMG_coarse_level_solver.cpp:9-62; one
+// solve per V-cycle, :64-76.  PARDISO itself is a supernodal LU over a nested-dissection ordering; this is the
+// same family of method laid out for the device: few dependent steps, dense blocks).
+//
+// The symmetrised graph of the operator is dissected recursively (separator = one level of a breadth-first level
+// structure rooted at a pseudo-peripheral vertex, thinned to the vertices that really touch the far side).  Every
+// tree node k owns a contiguous range of pivot rows P_k in the new numbering (descendants first, separator last)
+// and an update set U_k (sorted new indices > P_k: the ancestor rows its elimination touches).  The numeric
+// factorisation (device, nd_kernels.hip) is multifrontal: front F_k over P_k + U_k, D_k = F11 inverted
+// explicitly, and what a solve needs is kept per node as dense row-major blocks
+//     Lh_k = F21 D_k^-1         (u x p)   forward:   c[U_k] -= Lh_k c[P_k]      (pulled by the target rows)
+//     B_k  = [D_k^-1 | -D_k^-1 F12]  (p x (p + u))   backward:  x[P_k] = B_k [c[P_k]; x[U_k]]
+// A solve is one launch per tree level up (forward) and one per level down (backward): 2 * height + 1 dependent
+// launches, against ~ n / bandwidth for the block-tridiagonal chain.
+//
+// Pure host code, no HIP: tests/cpp/nd_plan_check.cpp runs the plan with a host emulation of the kernels.
+#pragma once
+
+#include <cstddef>
+#include <string>
+#include <vector>
+
+#include "host_setup.hpp"
+
+namespace sparsh {
+
+struct NdNode {
+    int first = 0, np = 0;   // pivot rows [first, first + np) in the new numbering
+    int nu = 0;              // size of the update set
+    int parent = -1;
+    int level = 0;           // height above the leaves (leaf = 0; parent = 1 + max over children)
+    int slot = 0;            // position among the children of its parent (extend-add passes run slot by slot)
+    size_t upd = 0;          // U_k = upd_idx[upd .. upd + nu)
+    size_t foff = 0;         // front (np + nu)^2, row-major, ld = np + nu                    (setup only)
+    size_t boff = 0;         // B_k, np x (np + nu)
+    size_t loff = 0;         // Lh_k, nu x np
+    size_t ioff = 0;         // gather list of the backward product: np + nu ints
+    size_t rel = 0;          // position of U_k[i] in the parent's front (rel_idx[rel + i])
+};
+
+struct NdSegment {           // one contribution to a forward target row: dot(Lh[moff .. moff + p), c[first .. first + p))
+    long long moff;
+    int first, p;
+};
+
+struct NdPlan {
+    int n = 0, leaf = 0;
+    int nlevels = 0, max_children = 0, max_np = 0;
+    std::vector<int> perm, inv;          // perm[new] = old, inv[old] = new
+    std::vector<NdNode> nodes;           // children before parents
+    std::vector<int> upd_idx, rel_idx;
+    std::vector<int> node_of_row;        // new row -> node
+    std::vector<std::vector<int>> level_nodes;  // nodes of each level
+    size_t front_doubles = 0, b_doubles = 0, l_doubles = 0, idx_ints = 0;
+    // entries of the permuted operator with their position in the fronts buffer (duplicates summed, sorted by position)
+    std::vector<long long> a_dst;
+    std::vector<double> a_val;
+    // forward: segments of every target row (CSR over new rows; rows of leaves have none)
+    std::vector<int> seg_ptr;
+    std::vector<NdSegment> segs;
+    size_t factor_bytes() const { return (b_doubles + l_doubles) * sizeof(double); }
+    size_t front_bytes() const { return front_doubles * sizeof(double); }
+};
+
+struct NdParams {
+    int leaf = 64;                 // largest subgraph kept as one dense pivot block
+    int max_pivot = 8192;          // largest pivot block (separator or unsplittable subgraph) accepted
+    size_t max_factor_bytes = (size_t)24 << 30;
+    size_t max_front_bytes = (size_t)48 << 30;
+};
+
+// false (err set) when the graph has a piece that cannot be dissected within the limits
+bool nd_make_plan(const HostCsr &A, const NdParams &prm, NdPlan &plan, std::string &err);
+
+}  // namespace sparsh

@@ -76,7 +76,9 @@ def run(grid=N_GRID, cfg=None, no_fold=False, layout_out=None, fem=0, idx16=None
                    "index16_blocks": b16, "row_blocks": nblk}, f)
 
 
-def collect(d):
+def collect(d, jacobi_kernel=None):
+    """jacobi_kernel: count only launches of this kernel as the measured sweep (the setup's placement search and the
+    solver launch other Jacobi kernels in the same process)."""
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
     out = {}
     for r in csv.DictReader(open(f)):
@@ -89,7 +91,8 @@ def collect(d):
         elif "copy_int_kernel" in name:
             key = "copy_int"
         elif ("sdia_kernel<2" in name or "sdia_tab_kernel<2" in name or "sdia_ord_kernel<2" in name or "sell_kernel<2" in name
-              or "csr_block_kernel<2" in name or "csr_rowlane_kernel<2" in name or "csr_rowlane16_kernel<2" in name) and ", 1>" in name:
+              or "csr_block_kernel<2" in name or "csr_rowlane_kernel<2" in name or "csr_rowlane16_kernel<2" in name) and ", 1>" in name \
+                and (jacobi_kernel is None or (jacobi_kernel + "<") in name):
             key = "jacobi"
             out["_kind"] = [3.0 if "sdia_" in name else (2.0 if "sell_kernel" in name else (1.0 if "rowlane16" in name else 0.0))]
         if key:
@@ -117,7 +120,7 @@ def collect_iterations(d):
     for r in rows[a + 1:b]:
         val = float(r["Counter_Value"]) * 1024.0
         total += val
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].replace("void ", "").replace("sparsh::", "").replace("(anonymous namespace)::", "").split("(")[0]
         e = by_kernel.setdefault(k, [0, 0.0])
         e[0] += 1
         e[1] += val
@@ -127,8 +130,12 @@ def collect_iterations(d):
 def summarize(fetch_dir, write_dir, out_path, grid=N_GRID, layout_path=None, quiet=False):
     n = grid ** 3
     nnz = 7 * n - 6 * grid ** 2
-    fetch, cnt = collect(fetch_dir)
-    write, _ = collect(write_dir)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lay_path = layout_path or os.path.join(root, "gpurun_out", "pmc_layout.json")
+    layout = json.load(open(lay_path)) if os.path.exists(lay_path) else None
+    jk = layout.get("kernel") if layout else None
+    fetch, cnt = collect(fetch_dir, jk)
+    write, _ = collect(write_dir, jk)
     known_read = {"axpby": 16 * n, "dot": 16 * n, "copy_int": 4 * n}
     known_write = {"axpby": 8 * n, "dot": 0, "copy_int": 4 * n}
     f8 = known_read["axpby"] / fetch["axpby"]      # 8-byte-per-lane loads
@@ -140,9 +147,6 @@ def summarize(fetch_dir, write_dir, out_path, grid=N_GRID, layout_path=None, qui
     # diagonals: no per-entry index (offsets/masks are per slot: < 1.5 % of the bytes, counted with
     # the 8-byte streams).  raw = bytes4/f4 + bytes8/f8  ->  solve for bytes8.
     pad_nnz = 7 * n
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lay_path = layout_path or os.path.join(root, "gpurun_out", "pmc_layout.json")
-    layout = json.load(open(lay_path)) if os.path.exists(lay_path) else None
     if layout and layout.get("nrow"):  # the matrix the --run pass actually used (e.g. the unstructured stand-in)
         n, nnz = layout["nrow"], layout["nnz"]
         known_read = {"axpby": 16 * n, "dot": 16 * n, "copy_int": 4 * n}
