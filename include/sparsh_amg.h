@@ -212,10 +212,22 @@ int sparsh_level_csr(sparsh_handle h, int level, int which, int *rowptr, int *co
  * place of Direct_Solver_Pardiso_solve); available after sparsh_setup_host when the coarsest level
  * has at most dense_limit rows */
 int sparsh_coarse_inverse(sparsh_handle h, double *inv);
-/* form of the coarsest-level direct solver: info6 = {rows, dense (1) or block-tridiagonal (0), block size,
+/* form of the coarsest-level direct solver: info6 = {rows, dense (1) or factored on the device (0), block size,
  * number of blocks, RCM bandwidth, hierarchy extended past max_levels (1/0)}; *bytes = HBM held by the
- * factors.  After sparsh_setup (block fields are 0 for the dense form or before the device setup). */
+ * factors.  After sparsh_setup (block fields are 0 unless the block-tridiagonal form is in use). */
 int sparsh_coarse_info(sparsh_handle h, int *info6, long *bytes);
+/* Which direct solver a coarsest level above dense_limit rows gets (both replace Direct_Solver_Pardiso,
+ * src/AMG_coarse_level_solver.cpp:9-76); call before sparsh_setup.
+ *   form 0 (default): nested-dissection multifrontal factorisation -- the operator's graph is dissected recursively, every
+ *     tree node's pivot block is inverted explicitly and its couplings to the ancestors are kept as dense blocks; a solve is
+ *     one launch per tree level upwards and one downwards (csrc/nd_plan.cpp, nd_solver.cpp, nd_kernels.hip).
+ *   form 1: block-tridiagonal factorisation of the RCM-ordered operator (csrc/coarse.cpp), ~ n / bandwidth dependent steps.
+ * leaf > 0: largest subgraph kept as one dense block (default 64); merge_rows >= 0: separators of successive bisections are
+ * eliminated as one pivot block while their total stays below this (default 192; 0 = plain bisection).
+ * sparsh_coarse_nd_info: info6 = {nested dissection in use (1/0), tree nodes, tree levels, largest pivot block,
+ * launches per solve, leaf size}. */
+int sparsh_set_coarse_form(sparsh_handle h, int form, int leaf, int merge_rows);
+int sparsh_coarse_nd_info(sparsh_handle h, int *info6);
 /* Interface form of the block-tridiagonal solve: where the RCM band is narrow against the block (2 * window <= block,
  * window = bandwidth rounded up to 64) only the first / last `window` rows of a block couple to its neighbours, so the
  * chain of dependent steps runs on those rows alone (products S_i^-1 A[i,neighbour] kept in HBM) and everything else is

@@ -109,6 +109,8 @@ def _load():
         "sparsh_coarse_window": (C.c_int, [H, c_int_p]),
         "sparsh_set_coarse_interface": (C.c_int, [H, C.c_int]),
         "sparsh_set_coarse_block": (C.c_int, [H, C.c_int]),
+        "sparsh_set_coarse_form": (C.c_int, [H, C.c_int, C.c_int, C.c_int]),
+        "sparsh_coarse_nd_info": (C.c_int, [H, c_int_p]),
         "sparsh_setup_seconds": (C.c_double, [H]),
         "sparsh_vcycle": (C.c_int, [H, c_dbl_p, c_dbl_p, C.c_int, c_dbl_p, C.c_int, c_int_p]),
         "sparsh_vcycle_dev": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int, c_dbl_p, C.c_int, c_int_p]),
@@ -414,14 +416,24 @@ class sp_matrix_mg:
         return inv
 
     def coarse_info(self):
-        """Form of the coarsest-level direct solver (dense inverse or block-tridiagonal factors)."""
+        """Form of the coarsest-level direct solver (dense inverse, nested-dissection or block-tridiagonal factors)."""
         info = (C.c_int * 6)()
         nbytes = C.c_long(0)
         _check(lib.sparsh_coarse_info(self._h, info, C.byref(nbytes)))
         win = C.c_int(0)
         _check(lib.sparsh_coarse_window(self._h, C.byref(win)))
-        return {"rows": info[0], "dense": bool(info[1]), "block": info[2], "nblocks": info[3], "bandwidth": info[4],
-                "extended": bool(info[5]), "bytes": nbytes.value, "window": win.value}
+        nd = (C.c_int * 6)()
+        _check(lib.sparsh_coarse_nd_info(self._h, nd))
+        form = "dense" if info[1] else ("nested_dissection" if nd[0] else ("block_tridiagonal" if info[3] else "not factored yet"))
+        return {"rows": info[0], "dense": bool(info[1]), "form": form, "block": info[2], "nblocks": info[3], "bandwidth": info[4],
+                "extended": bool(info[5]), "bytes": nbytes.value, "window": win.value,
+                "nd_nodes": nd[1], "nd_levels": nd[2], "nd_max_pivot": nd[3], "nd_launches_per_solve": nd[4], "nd_leaf": nd[5]}
+
+    def set_coarse_form(self, form="nd", leaf=0, merge_rows=-1):
+        """Direct solver of a coarsest level above dense_limit rows: "nd" (nested-dissection multifrontal, default) or "bt"
+        (block tridiagonal, round 2's); leaf / merge_rows tune the dissection (0 / -1 = defaults).  Call before setup."""
+        _check(lib.sparsh_set_coarse_form(self._h, {"nd": 0, "bt": 1}[form], int(leaf), int(merge_rows)))
+        return self
 
     def set_coarse_block(self, rows=0):
         """Block size of the block-tridiagonal coarse factorisation (0 = built-in rule); call before setup."""

@@ -456,7 +456,7 @@ int sparsh_coarse_inverse(sparsh_handle h, double *inv)
 {
     REQUIRE_HOST(h);
     const HostHierarchy &H = h->eng->host();
-    if (!H.coarse_dense) return fail(SPARSH_ESTATE, "the coarsest level is above dense_limit: it is factored on the device in block-tridiagonal form, no dense inverse exists");
+    if (!H.coarse_dense) return fail(SPARSH_ESTATE, "the coarsest level is above dense_limit: it is factored on the device (nested-dissection or block-tridiagonal form), no dense inverse exists");
     if (H.coarse_inverse.empty()) return fail(SPARSH_ESTATE, "host copy of the inverse was released by sparsh_setup; use sparsh_setup_host");
     std::memcpy(inv, H.coarse_inverse.data(), sizeof(double) * (size_t)H.nL * H.nL);
     return SPARSH_OK;
@@ -467,7 +467,7 @@ int sparsh_coarse_info(sparsh_handle h, int *info6, long *bytes)
     REQUIRE_HOST(h);
     const HostHierarchy &H = h->eng->host();
     const CoarseSolver &c = h->eng->coarse();
-    const bool bt = c.ready() && !c.dense();
+    const bool bt = c.ready() && !c.dense() && !c.nested();
     if (info6) {
         info6[0] = H.nL;
         info6[1] = H.coarse_dense ? 1 : 0;
@@ -485,6 +485,31 @@ int sparsh_set_coarse_interface(sparsh_handle h, int enable)
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
     h->eng->coarse_mut().set_allow_windowed(enable != 0);
     h->eng->coarse_mut().set_unrolled_chain(enable != 2);
+    return SPARSH_OK;
+}
+
+int sparsh_set_coarse_form(sparsh_handle h, int form, int leaf, int merge_rows)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    if (form != 0 && form != 1) return fail(SPARSH_EINVAL, "form must be 0 (nested dissection) or 1 (block tridiagonal)");
+    h->eng->coarse_mut().set_form(form);
+    h->eng->coarse_mut().set_nd_params(leaf, merge_rows);
+    return SPARSH_OK;
+}
+
+int sparsh_coarse_nd_info(sparsh_handle h, int *info6)
+{
+    REQUIRE_HOST(h);
+    const CoarseSolver &c = h->eng->coarse();
+    const bool nd = c.ready() && c.nested();
+    if (info6) {
+        info6[0] = nd ? 1 : 0;
+        info6[1] = nd ? c.nd().nnodes() : 0;
+        info6[2] = nd ? c.nd().nlevels() : 0;
+        info6[3] = nd ? c.nd().max_pivot_rows() : 0;
+        info6[4] = nd ? c.nd().launches_per_solve() : 0;
+        info6[5] = nd ? c.nd().leaf() : 0;
+    }
     return SPARSH_OK;
 }
 

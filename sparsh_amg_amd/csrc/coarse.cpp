@@ -49,6 +49,11 @@ bool bt_make_plan(const HostCsr &A, int target_blocks, int max_block, BtPlan &P,
               std::to_string(max_block) + "); lower coarse_limit so the hierarchy is extended instead";
         return false;
     }
+    if ((size_t)((n + B - 1) / B) * B * B * sizeof(double) > ((size_t)16 << 30)) {
+        err = "coarsest level too large for the block-tridiagonal device solve: " + std::to_string(n) + " rows in blocks of " + std::to_string(B) +
+              " would need more than 16 GB of factors; lower coarse_limit so the hierarchy is extended instead";
+        return false;
+    }
     P.B = B;
     P.nb = (n + B - 1) / B;
     P.mid = P.nb / 2;
@@ -86,6 +91,7 @@ bool bt_make_plan(const HostCsr &A, int target_blocks, int max_block, BtPlan &P,
 
 void CoarseSolver::release()
 {
+    nd_.release();
     for (void *p : allocs_) (void)hipFree(p);
     allocs_.clear();
     inv_ = sinv_ = z_ = nullptr;
@@ -403,9 +409,32 @@ bool CoarseSolver::setup_bt(const HostCsr &A, hipStream_t st, std::string &err, 
     return true;
 }
 
+bool CoarseSolver::probe(const HostCsr &A, std::string &err)
+{
+    if (form_ == 1) {
+        BtPlan P;
+        return bt_make_plan(A, 32, 6144, P, err, block_hint_);
+    }
+    return nd_.plan(A, nd_prm_, err);
+}
+
+bool CoarseSolver::setup_nd(const HostCsr &A, hipStream_t st, std::string &err, int *why_failed)
+{
+    release();
+    if (!nd_.setup(A, nd_prm_, st, err, why_failed)) return false;
+    n_ = A.nrow;
+    dense_ = false;
+    factor_seconds = nd_.plan_seconds + nd_.factor_seconds;
+    return true;
+}
+
 void CoarseSolver::solve(const double *b, double *x, hipStream_t st) const
 {
     if (n_ <= 0) return;
+    if (nd_.ready()) {
+        nd_.solve(b, x, st);
+        return;
+    }
     if (dense_) {
         launch_gemv(n_, inv_, b, x, st);
         return;

@@ -1,12 +1,14 @@
 // coarse.hpp -- coarsest-level direct solver on the device (stands where the reference calls
 // Direct_Solver_Pardiso: analyse + factor once, src/AMG_coarse_level_solver.cpp:9-62; one solve per
-// V-cycle, :64-76).  Two forms, chosen by the order of the system:
+// V-cycle, :64-76).  Three forms, chosen by the order of the system:
 //   n <= dense_limit : explicit dense inverse (host: RCM + banded LU), one GEMV per solve;
-//   larger           : block-tridiagonal ("twisted") factorisation of the RCM-ordered operator, kept as
+//   larger (default) : nested-dissection multifrontal factorisation (nd_plan.hpp, nd_solver.hpp, nd_kernels.hip):
+//                      2 x (tree height) dependent launches per solve, factors of O(n^(4/3)) (3D) / O(n log n) (2D);
+//   larger (form 1)  : block-tridiagonal ("twisted") factorisation of the RCM-ordered operator, kept as
 //                      the explicit inverses of the Schur-complement diagonal blocks in HBM, factored and
-//                      applied by the kernels of coarse_kernels.hip.  This is what lets the reference's
-//                      level1 = 6 policy (coarsest level = N/32 rows, src/AMG_phases.cpp:51,77) run on
-//                      the device.
+//                      applied by the kernels of coarse_kernels.hip (round 2's solver: ~ n / bandwidth dependent steps).
+// Either of the last two is what lets the reference's level1 = 6 policy (coarsest level = N/32 rows,
+// src/AMG_phases.cpp:51,77) run on the device.
 #pragma once
 
 #include <hip/hip_runtime_api.h>
@@ -15,6 +17,7 @@
 #include <vector>
 
 #include "host_setup.hpp"
+#include "nd_solver.hpp"
 
 namespace sparsh {
 
@@ -62,12 +65,28 @@ public:
     // block-tridiagonal form: plan on the host, factor on the device (stream st; synchronises once at the end).
     // why_failed: 1 the operator has no usable band structure, 2 singular, 3 device error
     bool setup_bt(const HostCsr &A, hipStream_t st, std::string &err, int *why_failed = nullptr);
+    // host-only check that the configured form accepts the operator (band / separators, memory budget); the nested-dissection
+    // plan is kept for setup_nd
+    bool probe(const HostCsr &A, std::string &err);
+    // nested-dissection multifrontal form (default above dense_limit); why_failed as for setup_bt
+    bool setup_nd(const HostCsr &A, hipStream_t st, std::string &err, int *why_failed = nullptr);
     // x = A^-1 b, device vectors in the operator's own numbering; enqueues on st
     void solve(const double *b, double *x, hipStream_t st) const;
     void release();
 
     bool ready() const { return n_ > 0; }
     bool dense() const { return dense_; }
+    bool nested() const { return nd_.ready(); }
+    const NdSolver &nd() const { return nd_; }
+    // 0 = nested dissection above dense_limit (default), 1 = block-tridiagonal (round 2's solver, kept for A/B runs)
+    void set_form(int form) { form_ = form; }
+    int form() const { return form_; }
+    void set_nd_params(int leaf, int merge_rows)
+    {
+        if (leaf > 0) nd_prm_.leaf = leaf;
+        if (merge_rows >= 0) nd_prm_.merge_rows = merge_rows;
+    }
+    const NdParams &nd_params() const { return nd_prm_; }
     int n() const { return n_; }
     int block() const { return plan_.B; }
     int nblocks() const { return plan_.nb; }
@@ -79,10 +98,17 @@ public:
     void set_unrolled_chain(bool on) { unroll_chain_ = on; }  // interface form: chain passes as triangular products (default) or step by step
     bool unrolled() const { return unrolled_; }
     const double *dense_inverse() const { return inv_; }
-    size_t bytes() const { return dense_ ? (size_t)n_ * n_ * 8 : plan_.sinv_bytes() + (windowed_ ? (size_t)2 * plan_.nb * plan_.B * win_ * 8 : 0) + tri_bytes_; }
+    size_t bytes() const
+    {
+        if (nd_.ready()) return nd_.bytes();
+        return dense_ ? (size_t)n_ * n_ * 8 : plan_.sinv_bytes() + (windowed_ ? (size_t)2 * plan_.nb * plan_.B * win_ * 8 : 0) + tri_bytes_;
+    }
     double factor_seconds = 0.0;
 
 private:
+    NdSolver nd_;
+    NdParams nd_prm_;
+    int form_ = 0;
     bool allow_windowed_ = true, unroll_chain_ = true;
     int block_hint_ = 0;
     int n_ = 0;

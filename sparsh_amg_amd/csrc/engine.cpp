@@ -482,6 +482,30 @@ int Engine::setup_host(const sparsh_params &p)
         return SPARSH_ENUMERIC;
     }
     setup_seconds = H_.seconds;
+    if (!H_.coarse_dense) {
+        // The device direct solver may refuse what max_levels left over (no usable separators / band, factors beyond the memory
+        // budget -- e.g. a coarsening that stalled far above limit_upper).  Then the hierarchy is extended by the reference's own
+        // coarsening rule instead of failing: coarse_limit = dense_limit, the behaviour before the reference policy became the default.
+        const double tp = omp_get_wtime();
+        std::string perr;
+        if (!coarse_.probe(H_.levels.back().A, perr)) {
+            if (sp.print) std::printf("note: %s -- extending the hierarchy instead\n", perr.c_str());
+            SetupParams sp2 = sp;
+            sp2.coarse_limit = sp.dense_limit;
+            const double before = H_.seconds;
+            if (!build_hierarchy(A0_, sp2, H_)) {
+                error = H_.error;
+                return SPARSH_ENUMERIC;
+            }
+            H_.seconds += before;
+            if (!H_.coarse_dense && !coarse_.probe(H_.levels.back().A, perr)) {
+                error = perr;
+                return SPARSH_EINVAL;
+            }
+        }
+        H_.seconds += omp_get_wtime() - tp;
+        setup_seconds = H_.seconds;
+    }
     host_ready_ = true;
     return SPARSH_OK;
 }
@@ -883,11 +907,18 @@ int Engine::setup(const sparsh_params &p)
         // factorisation on the device
         const double t_f = omp_get_wtime();
         int why = 0;
-        if (!coarse_.setup_bt(H_.levels.back().A, st_, error, &why)) return why == 1 ? SPARSH_EINVAL : (why == 2 ? SPARSH_ENUMERIC : SPARSH_ENODEV);
+        const bool okc = coarse_.form() == 1 ? coarse_.setup_bt(H_.levels.back().A, st_, error, &why) : coarse_.setup_nd(H_.levels.back().A, st_, error, &why);
+        if (!okc) return why == 1 ? SPARSH_EINVAL : (why == 2 ? SPARSH_ENUMERIC : SPARSH_ENODEV);
         setup_seconds += omp_get_wtime() - t_f;
-        if (p.print_setup && (G == 1 || me == 0))
-            std::printf("coarsest level: %d rows, RCM bandwidth %d -> %d blocks of %d, factors %.1f MB in HBM, %.2f s\n", nL_, coarse_.bandwidth(),
-                        coarse_.nblocks(), coarse_.block(), coarse_.bytes() / 1e6, coarse_.factor_seconds);
+        if (p.print_setup && (G == 1 || me == 0)) {
+            if (coarse_.nested())
+                std::printf("coarsest level: %d rows, nested dissection: %d nodes on %d levels (largest pivot block %d), factors %.1f MB in HBM, %d launches per solve, %.2f s\n",
+                            nL_, coarse_.nd().nnodes(), coarse_.nd().nlevels(), coarse_.nd().max_pivot_rows(), coarse_.bytes() / 1e6,
+                            coarse_.nd().launches_per_solve(), coarse_.factor_seconds);
+            else
+                std::printf("coarsest level: %d rows, RCM bandwidth %d -> %d blocks of %d, factors %.1f MB in HBM, %.2f s\n", nL_, coarse_.bandwidth(),
+                            coarse_.nblocks(), coarse_.block(), coarse_.bytes() / 1e6, coarse_.factor_seconds);
+        }
     }
 
     part_cap_ = max_blk + 8;

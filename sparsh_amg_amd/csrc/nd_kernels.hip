@@ -1,0 +1,374 @@
+// nd_kernels.hip -- device kernels of the nested-dissection multifrontal coarse solver (nd_plan.hpp, nd_solver.hpp).
+// Replaces Direct_Solver_Pardiso (src/AMG_coarse_level_solver.cpp:9-76) on coarsest levels above dense_limit rows.
+//
+// Factorisation, one tree level at a time from the leaves up (all nodes of a level in the same launches):
+//   scatter      entries of the permuted operator -> fronts (once)
+//   extend-add   F_parent[rel, rel] += F22 of each child, one pass per child slot (so two children never race)
+//   invert       D^-1 of the pivot block, Gauss-Jordan with partial pivoting inside the block (one workgroup per node;
+//                pivot blocks above kNdSmallPivot rows go through the whole-chip inversion of coarse_kernels.hip)
+//   gemm         -D^-1 F12 -> B_k ; F21 D^-1 -> Lh_k ; F22 += F21 (-D^-1 F12)      (batched 64 x 64 tiles, fp64)
+// Solve (2 * levels launches): c = b[perm]; per level upwards c[r] -= sum over segments Lh.c ; per level downwards
+// x[P_k] = B_k [c[P_k]; x[U_k]], scattered back to the caller's numbering.  No atomics: every sum has a fixed order.
+#include <hip/hip_runtime.h>
+
+#include "nd_solver.hpp"
+
+namespace sparsh {
+
+namespace {
+
+constexpr int kNB = 256;
+
+__device__ __forceinline__ double nd_wsum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(kNB) void nd_scatter_kernel(long long cnt, const long long *__restrict__ dst, const double *__restrict__ val,
+                                                         double *__restrict__ fronts)
+{
+    for (long long i = (long long)blockIdx.x * kNB + threadIdx.x; i < cnt; i += (long long)gridDim.x * kNB) fronts[dst[i]] = val[i];
+}
+
+// blockIdx.x = child in the pass, blockIdx.y = chunk of 4 rows of its update block (one wave per row)
+__global__ __launch_bounds__(kNB) void nd_extend_add_kernel(const NdDevNode *__restrict__ nodes, const int *__restrict__ children,
+                                                            const int *__restrict__ rel_idx, double *__restrict__ fronts)
+{
+    const NdDevNode c = nodes[children[blockIdx.x]];
+    const int i = blockIdx.y * (kNB / 64) + (threadIdx.x >> 6);
+    if (i >= c.nu) return;
+    const NdDevNode p = nodes[c.parent];
+    const int lane = threadIdx.x & 63;
+    const int ldc = c.np + c.nu, ldp = p.np + p.nu;
+    const int *__restrict__ rel = rel_idx + c.rel;
+    const double *__restrict__ src = fronts + c.foff + (size_t)(c.np + i) * ldc + c.np;
+    double *__restrict__ dst = fronts + p.foff + (size_t)rel[i] * ldp;
+    for (int j = lane; j < c.nu; j += 64) dst[rel[j]] += src[j];
+}
+
+// In-place Gauss-Jordan inversion with partial pivoting of the pivot block (np x np at the top left of the front, leading
+// dimension np + nu) of one node per workgroup; the inverse goes to the first np columns of B_k (same leading dimension).
+//   step k: p = argmax_{i >= k} |M[i][k]| (lowest index on ties); rows k, p swapped; row k scaled by 1 / pivot with
+//   M[k][k] = 1 / pivot; every other row i: M[i][j] -= f_i * M[k][j], M[i][k] = -f_i / pivot  (f_i = old M[i][k]).
+//   (PA)^-1 = A^-1 P^-1: the columns are swapped back in reverse pivot order at the end.
+constexpr int kInvThreads = 1024;
+
+__global__ __launch_bounds__(kInvThreads) void nd_invert_kernel(const NdDevNode *__restrict__ nodes, const int *__restrict__ list,
+                                                               double *__restrict__ fronts, double *__restrict__ Bm, int *__restrict__ singular)
+{
+    __shared__ double prow[kNdSmallPivot], fcol[kNdSmallPivot];
+    __shared__ int cm[kNdSmallPivot], pivs[kNdSmallPivot];
+    __shared__ double smax[kInvThreads / 64];
+    __shared__ int sidx[kInvThreads / 64];
+    __shared__ int s_p;
+    const NdDevNode nd = nodes[list[blockIdx.x]];
+    const int p = nd.np, ld = nd.np + nd.nu;
+    if (p > kNdSmallPivot) return;
+    double *__restrict__ M = fronts + nd.foff;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int k = 0; k < p; ++k) {
+        double best = -1.0;
+        int bi = k;
+        {
+            const int i = k + tid;  // p <= kInvThreads: one candidate per thread
+            if (i < p) {
+                best = fabs(M[(size_t)i * ld + k]);
+                bi = i;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ob = __shfl_down(best, off, 64);
+            const int oi = __shfl_down(bi, off, 64);
+            if (ob > best || (ob == best && oi < bi)) {
+                best = ob;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            smax[wv] = best;
+            sidx[wv] = bi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double b = smax[0];
+            int ix = sidx[0];
+            for (int q = 1; q < kInvThreads / 64; ++q)
+                if (smax[q] > b || (smax[q] == b && sidx[q] < ix)) {
+                    b = smax[q];
+                    ix = sidx[q];
+                }
+            s_p = ix;
+            pivs[k] = ix;
+            if (!(b > 0.0)) *singular = 1;
+        }
+        __syncthreads();
+        const int pv = s_p;
+        if (pv != k)
+            for (int j = tid; j < p; j += kInvThreads) {
+                const double a = M[(size_t)k * ld + j], b = M[(size_t)pv * ld + j];
+                M[(size_t)k * ld + j] = b;
+                M[(size_t)pv * ld + j] = a;
+            }
+        __syncthreads();
+        const double rpiv = 1.0 / M[(size_t)k * ld + k];
+        for (int j = tid; j < p; j += kInvThreads) {
+            prow[j] = (j == k) ? rpiv : M[(size_t)k * ld + j] * rpiv;
+            fcol[j] = M[(size_t)j * ld + k];
+        }
+        __syncthreads();
+        for (int i = wv; i < p; i += kInvThreads / 64) {
+            double *__restrict__ row = M + (size_t)i * ld;
+            if (i == k) {
+                for (int j = lane; j < p; j += 64) row[j] = prow[j];
+            } else {
+                const double f = fcol[i];
+                for (int j = lane; j < p; j += 64) row[j] = (j == k) ? -f * rpiv : row[j] - f * prow[j];
+            }
+        }
+        __syncthreads();
+    }
+    for (int j = tid; j < p; j += kInvThreads) cm[j] = j;
+    __syncthreads();
+    if (tid == 0)
+        for (int k = p - 1; k >= 0; --k) {
+            const int q = pivs[k];
+            const int t = cm[k];
+            cm[k] = cm[q];
+            cm[q] = t;
+        }
+    __syncthreads();
+    double *__restrict__ out = Bm + nd.boff;
+    for (int i = wv; i < p; i += kInvThreads / 64)
+        for (int j = lane; j < p; j += 64) out[(size_t)i * ld + j] = M[(size_t)i * ld + cm[j]];
+}
+
+__global__ __launch_bounds__(kNB) void nd_copy_block_kernel(const double *__restrict__ src, int lds, double *__restrict__ dst, int ldd, int rows,
+                                                            int cols)
+{
+    const int i = blockIdx.x;
+    if (i >= rows) return;
+    for (int j = threadIdx.x; j < cols; j += kNB) dst[(size_t)i * ldd + j] = src[(size_t)i * lds + j];
+}
+
+// batched GEMM, one 64 x 64 tile of one problem per workgroup, K in steps of 16 through LDS, 4 x 4 results per thread
+constexpr int kTM = 64, kTN = 64, kTK = 16;
+
+__global__ __launch_bounds__(kNB) void nd_gemm_kernel(const NdGemm *__restrict__ problems, const int *__restrict__ tiles)
+{
+    __shared__ double As[kTK][kTM + 1];
+    __shared__ double Bs[kTK][kTN + 1];
+    const NdGemm g = problems[tiles[2 * blockIdx.x]];
+    const int tile = tiles[2 * blockIdx.x + 1];
+    const int m0 = (tile / g.tiles_n) * kTM, n0 = (tile % g.tiles_n) * kTN;
+    const int t = threadIdx.x;
+    const int ty = t >> 4, tx = t & 15;
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    const int ar = t >> 2, ak = (t & 3) * 4;    // A tile: row ar, k offsets ak .. ak + 3
+    const int bk = t >> 4, bc = (t & 15) * 4;   // B tile: k row bk, columns bc .. bc + 3
+    for (int k0 = 0; k0 < g.K; k0 += kTK) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int gm = m0 + ar, gk = k0 + ak + q;
+            As[ak + q][ar] = (gm < g.M && gk < g.K) ? g.a[(size_t)gm * g.lda + gk] : 0.0;
+            const int gk2 = k0 + bk, gn = n0 + bc + q;
+            Bs[bk][bc + q] = (gk2 < g.K && gn < g.N) ? g.b[(size_t)gk2 * g.ldb + gn] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < kTK; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gm = m0 + ty * 4 + i;
+        if (gm >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gn = n0 + tx * 4 + j;
+            if (gn >= g.N) continue;
+            double *cp = g.c + (size_t)gm * g.ldc + gn;
+            const double v = g.alpha * acc[i][j];
+            *cp = g.beta ? *cp + v : v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kNB) void nd_permute_kernel(int n, const int *__restrict__ perm, const double *__restrict__ b, double *__restrict__ c)
+{
+    const int i = blockIdx.x * kNB + threadIdx.x;
+    if (i < n) c[i] = b[perm[i]];
+}
+
+// forward, one tree level: c[r] -= sum over the row's segments of Lh[moff .. moff + p) . c[first .. first + p)
+// WIDE = false: one wave per row; true: one workgroup per row (long rows of the top separators)
+template <bool WIDE>
+__global__ __launch_bounds__(kNB) void nd_forward_kernel(const int *__restrict__ rows, int nrows, const int *__restrict__ seg_ptr,
+                                                         const NdSegment *__restrict__ segs, const double *__restrict__ Lm, double *__restrict__ c)
+{
+    __shared__ double part[kNB / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = WIDE ? blockIdx.x : blockIdx.x * (kNB / 64) + wv;
+    if (q >= nrows) return;
+    const int r = rows[q];
+    const int s0 = seg_ptr[r], s1 = seg_ptr[r + 1];
+    const int tid = WIDE ? threadIdx.x : lane;
+    constexpr int STR = WIDE ? kNB : 64;
+    double a0 = 0.0, a1 = 0.0;
+    int s = s0;
+    for (; s + 1 < s1; s += 2) {  // two segments at a time: their loads are independent
+        const NdSegment g0 = segs[s], g1 = segs[s + 1];
+        const double *__restrict__ m0 = Lm + g0.moff, *__restrict__ m1 = Lm + g1.moff;
+        const double *__restrict__ v0 = c + g0.first, *__restrict__ v1 = c + g1.first;
+        const int pm = g0.p > g1.p ? g0.p : g1.p;
+        for (int t = tid; t < pm; t += STR) {
+            const double x0 = t < g0.p ? m0[t] * v0[t] : 0.0;
+            const double x1 = t < g1.p ? m1[t] * v1[t] : 0.0;
+            a0 += x0;
+            a1 += x1;
+        }
+    }
+    if (s < s1) {
+        const NdSegment g0 = segs[s];
+        const double *__restrict__ m0 = Lm + g0.moff;
+        const double *__restrict__ v0 = c + g0.first;
+        for (int t = tid; t < g0.p; t += STR) a0 += m0[t] * v0[t];
+    }
+    double acc = nd_wsum(a0 + a1);
+    if (WIDE) {
+        if (lane == 0) part[wv] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) c[r] -= (part[0] + part[1]) + (part[2] + part[3]);
+    } else if (lane == 0) {
+        c[r] -= acc;
+    }
+}
+
+// backward, one tree level: x[r] = B_k[row] . [c[P_k]; x[U_k]] through the node's gather list (w = [c | x], both in the new
+// numbering), written to w and, through perm, to the caller's vector
+template <bool WIDE>
+__global__ __launch_bounds__(kNB) void nd_backward_kernel(const int *__restrict__ rows, const int *__restrict__ rnode, int nrows, int n,
+                                                          const NdDevNode *__restrict__ nodes, const int *__restrict__ idx,
+                                                          const double *__restrict__ Bm, double *__restrict__ w, const int *__restrict__ perm,
+                                                          double *__restrict__ x)
+{
+    __shared__ double part[kNB / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = WIDE ? blockIdx.x : blockIdx.x * (kNB / 64) + wv;
+    if (q >= nrows) return;
+    const int r = rows[q];
+    const NdDevNode nd = nodes[rnode[q]];
+    const int len = nd.np + nd.nu;
+    const double *__restrict__ row = Bm + nd.boff + (size_t)(r - nd.first) * len;
+    const int *__restrict__ ix = idx + nd.ioff;
+    const int tid = WIDE ? threadIdx.x : lane;
+    constexpr int STR = WIDE ? kNB : 64;
+    constexpr int U = 4;
+    double acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = 0.0;
+    for (int t0 = tid; t0 < len; t0 += U * STR) {
+        double m[U];
+        int g[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + u * STR;
+            const bool on = t < len;
+            m[u] = on ? row[t] : 0.0;
+            g[u] = on ? ix[t] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + u * STR;
+            acc[u] += t < len ? m[u] * w[g[u]] : 0.0;
+        }
+    }
+    double a = nd_wsum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+    if (WIDE) {
+        if (lane == 0) part[wv] = a;
+        __syncthreads();
+        a = (part[0] + part[1]) + (part[2] + part[3]);
+        if (threadIdx.x != 0) return;
+    } else if (lane != 0) {
+        return;
+    }
+    w[n + r] = a;
+    x[perm[r]] = a;
+}
+
+}  // namespace
+
+void nd_launch_scatter(long long cnt, const long long *dst, const double *val, double *fronts, hipStream_t st)
+{
+    if (cnt <= 0) return;
+    long long g = (cnt + kNB - 1) / kNB;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(nd_scatter_kernel, dim3((unsigned)g), dim3(kNB), 0, st, cnt, dst, val, fronts);
+}
+
+void nd_launch_extend_add(const NdDevNode *nodes, const int *children, int nchildren, int max_nu, const int *rel_idx, double *fronts, hipStream_t st)
+{
+    if (nchildren <= 0 || max_nu <= 0) return;
+    hipLaunchKernelGGL(nd_extend_add_kernel, dim3(nchildren, (max_nu + kNB / 64 - 1) / (kNB / 64)), dim3(kNB), 0, st, nodes, children, rel_idx, fronts);
+}
+
+void nd_launch_invert(const NdDevNode *nodes, const int *list, int count, double *fronts, double *Bm, int *singular, hipStream_t st)
+{
+    if (count <= 0) return;
+    hipLaunchKernelGGL(nd_invert_kernel, dim3(count), dim3(kInvThreads), 0, st, nodes, list, fronts, Bm, singular);
+}
+
+void nd_launch_copy_block(const double *src, int lds, double *dst, int ldd, int rows, int cols, hipStream_t st)
+{
+    if (rows <= 0 || cols <= 0) return;
+    hipLaunchKernelGGL(nd_copy_block_kernel, dim3(rows), dim3(kNB), 0, st, src, lds, dst, ldd, rows, cols);
+}
+
+void nd_launch_gemm(const NdGemm *problems, const int *tiles, int ntiles, hipStream_t st)
+{
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(nd_gemm_kernel, dim3(ntiles), dim3(kNB), 0, st, problems, tiles);
+}
+
+void nd_launch_permute(int n, const int *perm, const double *b, double *c, hipStream_t st)
+{
+    hipLaunchKernelGGL(nd_permute_kernel, dim3((n + kNB - 1) / kNB), dim3(kNB), 0, st, n, perm, b, c);
+}
+
+void nd_launch_forward(const int *rows, int nrows, bool wide, const int *seg_ptr, const NdSegment *segs, const double *Lm, double *c, hipStream_t st)
+{
+    if (nrows <= 0) return;
+    if (wide)
+        hipLaunchKernelGGL(nd_forward_kernel<true>, dim3(nrows), dim3(kNB), 0, st, rows, nrows, seg_ptr, segs, Lm, c);
+    else
+        hipLaunchKernelGGL(nd_forward_kernel<false>, dim3((nrows + kNB / 64 - 1) / (kNB / 64)), dim3(kNB), 0, st, rows, nrows, seg_ptr, segs, Lm, c);
+}
+
+void nd_launch_backward(const int *rows, const int *rnode, int nrows, bool wide, int n, const NdDevNode *nodes, const int *idx, const double *Bm,
+                        double *w, const int *perm, double *x, hipStream_t st)
+{
+    if (nrows <= 0) return;
+    if (wide)
+        hipLaunchKernelGGL(nd_backward_kernel<true>, dim3(nrows), dim3(kNB), 0, st, rows, rnode, nrows, n, nodes, idx, Bm, w, perm, x);
+    else
+        hipLaunchKernelGGL(nd_backward_kernel<false>, dim3((nrows + kNB / 64 - 1) / (kNB / 64)), dim3(kNB), 0, st, rows, rnode, nrows, n, nodes, idx, Bm, w,
+                           perm, x);
+}
+
+}  // namespace sparsh

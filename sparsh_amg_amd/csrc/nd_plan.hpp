@@ -65,6 +65,7 @@ struct NdPlan {
 
 struct NdParams {
     int leaf = 64;                 // largest subgraph kept as one dense pivot block
+    int merge_rows = 192;          // separators of successive bisections are eliminated as ONE pivot block while their total stays below
     int max_pivot = 8192;          // largest pivot block (separator or unsplittable subgraph) accepted
     size_t max_factor_bytes = (size_t)24 << 30;
     size_t max_front_bytes = (size_t)48 << 30;

@@ -1,0 +1,84 @@
+// nd_solver.hpp -- device side of the nested-dissection multifrontal coarse solver (plan: nd_plan.hpp).
+// Stands where the reference calls PARDISO (src/AMG_coarse_level_solver.cpp:9-62 analyse + factor, :64-76 solve).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "nd_plan.hpp"
+
+namespace sparsh {
+
+struct NdDevNode {
+    long long foff, boff, loff, ioff;
+    int first, np, nu, rel;  // rel: offset of this node's row positions in its parent's front (rel_idx)
+    int parent, pad;
+};
+
+struct NdGemm {  // C (M x N) = alpha * A (M x K) * B (K x N) + (beta ? C : 0), all row-major
+    const double *a, *b;
+    double *c;
+    int lda, ldb, ldc, M, N, K;
+    double alpha;
+    int beta, tiles_n;
+};
+
+class NdSolver {
+public:
+    ~NdSolver() { release(); }
+    NdSolver() = default;
+    NdSolver(const NdSolver &) = delete;
+    NdSolver &operator=(const NdSolver &) = delete;
+
+    // host half alone (no device): dissect, size the factors; false when the operator is refused.  The plan is kept for setup().
+    bool plan(const HostCsr &A, const NdParams &prm, std::string &err);
+    // why_failed: 1 the plan was refused (graph / memory limits), 2 singular, 3 device error
+    bool setup(const HostCsr &A, const NdParams &prm, hipStream_t st, std::string &err, int *why_failed);
+    void solve(const double *b, double *x, hipStream_t st) const;  // device vectors, the operator's own numbering
+    void release();
+
+    bool ready() const { return n_ > 0; }
+    int n() const { return n_; }
+    int nlevels() const { return nlevels_; }
+    int nnodes() const { return nnodes_; }
+    int leaf() const { return leaf_; }
+    int max_pivot_rows() const { return max_np_; }
+    int launches_per_solve() const { return launches_; }
+    size_t bytes() const { return factor_bytes_; }
+    double factor_seconds = 0.0, plan_seconds = 0.0;
+
+private:
+    std::unique_ptr<NdPlan> pending_;  // plan() ran ahead of setup()
+    const void *pending_key_ = nullptr;
+    int n_ = 0, nlevels_ = 0, nnodes_ = 0, leaf_ = 0, max_np_ = 0, launches_ = 0;
+    size_t factor_bytes_ = 0;
+    std::vector<void *> allocs_;
+    double *Bm_ = nullptr, *Lm_ = nullptr, *w_ = nullptr;
+    int *perm_ = nullptr, *idx_ = nullptr, *seg_ptr_ = nullptr;
+    NdSegment *segs_ = nullptr;
+    NdDevNode *nodes_ = nullptr;
+    struct Level {
+        int *rows = nullptr;   // new row indices of the level's pivot rows
+        int *rnode = nullptr;  // node of each of them
+        int nrows = 0;
+        bool wide_fwd = false, wide_bwd = false;  // one workgroup per row instead of one wave per row
+    };
+    std::vector<Level> lev_;
+};
+
+// launchers of nd_kernels.hip
+void nd_launch_scatter(long long cnt, const long long *dst, const double *val, double *fronts, hipStream_t st);
+void nd_launch_extend_add(const NdDevNode *nodes, const int *children, int nchildren, int max_nu, const int *rel_idx, double *fronts, hipStream_t st);
+void nd_launch_invert(const NdDevNode *nodes, const int *list, int count, double *fronts, double *Bm, int *singular, hipStream_t st);
+void nd_launch_copy_block(const double *src, int lds, double *dst, int ldd, int rows, int cols, hipStream_t st);
+void nd_launch_gemm(const NdGemm *problems, const int *tiles, int ntiles, hipStream_t st);
+void nd_launch_permute(int n, const int *perm, const double *b, double *c, hipStream_t st);
+void nd_launch_forward(const int *rows, int nrows, bool wide, const int *seg_ptr, const NdSegment *segs, const double *Lm, double *c, hipStream_t st);
+void nd_launch_backward(const int *rows, const int *rnode, int nrows, bool wide, int n, const NdDevNode *nodes, const int *idx, const double *Bm,
+                        double *w, const int *perm, double *x, hipStream_t st);
+constexpr int kNdSmallPivot = 1024;  // largest pivot block the one-workgroup inversion takes
+
+}  // namespace sparsh

@@ -3,9 +3,11 @@ reference's own level policy on the device.  GPU box only.
 
 The reference stops coarsening after level1 = 6 levels and hands whatever is left to PARDISO
 (/root/reference/src/AMG_phases.cpp:51,77,89; src/AMG_coarse_level_solver.cpp:64-76): 31 250 rows at
-100^3.  The device solves such a level with a block-tridiagonal factorisation of the RCM-ordered
-operator (explicit inverses of the Schur-complement diagonal blocks, factored and applied on the
-GPU).  Checked here: the solver against scipy's sparse LU, and the only >= 1 M-row vector captured
+100^3.  The device solves such a level with a nested-dissection multifrontal factorisation (default since
+round 3: csrc/nd_plan.cpp, nd_solver.cpp, nd_kernels.hip) or with round 2's block-tridiagonal
+factorisation of the RCM-ordered operator (form "bt": explicit inverses of the Schur-complement diagonal
+blocks), both factored and applied on the GPU.  Checked here: both solvers against scipy's sparse LU,
+the fall-back when a coarsest level is refused, and the only >= 1 M-row vector captured
 from the reference (SURVEY Appendix A.2, 100^3: 6 levels, 21 PCG iterations, 65 AMG cycles) on the
 HIP path to the SURVEY §8d tolerance.
 """
@@ -61,7 +63,7 @@ def _nonsym2d(m):
 def test_block_tridiagonal_solver_vs_sparse_lu(name, gen, interface):
     rp, ci, v = gen()
     n = len(rp) - 1
-    A = sa.sp_matrix_mg(rp, ci, v).set_coarse_interface(interface).setup(sa.default_params(**QUIET, **ONE_LEVEL, dense_limit=2000))
+    A = sa.sp_matrix_mg(rp, ci, v).set_coarse_form("bt").set_coarse_interface(interface).setup(sa.default_params(**QUIET, **ONE_LEVEL, dense_limit=2000))
     try:
         info = A.coarse_info()
         assert A.nlevels == 1 and info["rows"] == n and not info["dense"]
@@ -88,8 +90,87 @@ def test_block_tridiagonal_solver_vs_sparse_lu(name, gen, interface):
         A.close()
 
 
+def _fem(npts):
+    return problems.fem_unstructured(npts)
+
+
+@pytest.mark.parametrize("name,gen,leaf,merge", [
+    ("p3d_24", lambda: problems.poisson3d(24), 0, -1),            # 13 824 rows, defaults (leaf 64, merged separators up to 192 rows)
+    ("p3d_24_plain_bisection", lambda: problems.poisson3d(24), 16, 0),   # small leaves, no merging: a deep tree
+    ("p3d_24_big_blocks", lambda: problems.poisson3d(24), 200, 600),      # few levels, wide pivot blocks
+    ("p2d_150", lambda: problems.poisson2d(150), 0, -1),
+    ("nonsym2d_170", lambda: _nonsym2d(170), 0, -1),               # 28 900 rows, nonsymmetric
+    ("nonsym3d_22", lambda: _nonsym3d(22), 0, -1),                 # not diagonally dominant: pivoting inside the pivot blocks
+    ("p3d_ragged", lambda: problems.poisson3d(21), 32, 100),
+    ("fem_20000", lambda: _fem(20000), 0, -1),                     # unstructured P1-FEM mesh: irregular separators, many children per node
+    ("p3d_40_top_separator_above_1024_rows", lambda: problems.poisson3d(40), 0, -1),  # 64 000 rows: the top pivot block takes the whole-chip inversion
+])
+def test_nested_dissection_solver_vs_sparse_lu(name, gen, leaf, merge):
+    rp, ci, v = gen()
+    n = len(rp) - 1
+    A = sa.sp_matrix_mg(rp, ci, v).set_coarse_form("nd", leaf, merge).setup(sa.default_params(**QUIET, **ONE_LEVEL, dense_limit=2000))
+    try:
+        info = A.coarse_info()
+        assert A.nlevels == 1 and info["rows"] == n and not info["dense"] and info["form"] == "nested_dissection"
+        assert info["nd_levels"] >= 2 and info["nd_launches_per_solve"] == 2 * info["nd_levels"]
+        assert info["nd_leaf"] == (leaf or 64)
+        if "above_1024" in name:
+            assert info["nd_max_pivot"] > 1024
+        if "plain_bisection" in name:
+            assert info["nd_levels"] > 8
+        S = sp.csr_matrix((v, ci, rp), shape=(n, n))
+        lu = spla.splu(S.tocsc())
+        rng = np.random.default_rng(1)
+        for b in (np.ones(n), rng.standard_normal(n)):
+            x = A.op_coarse(b)
+            xr = lu.solve(b)
+            assert np.linalg.norm(x - xr) <= 1e-11 * np.linalg.norm(xr), name
+            assert np.linalg.norm(b - S @ x) <= 1e-11 * np.linalg.norm(b)
+        # deterministic: no atomics anywhere in the factorisation or the solve
+        assert np.array_equal(A.op_coarse(np.ones(n)), A.op_coarse(np.ones(n)))
+    finally:
+        A.close()
+
+
+def test_nested_dissection_and_block_tridiagonal_agree_in_a_solve():
+    """Same hierarchy (the reference's 6 levels on 64^3: 8192-row coarsest level), coarsest level through either device factorisation."""
+    rp, ci, v = problems.poisson3d(64)
+    b = np.ones(len(rp) - 1)
+    hs, xs = [], []
+    for form in ("nd", "bt"):
+        A = sa.sp_matrix_mg(rp, ci, v).set_coarse_form(form).setup(sa.default_params(**QUIET, dense_limit=4000))
+        info = A.coarse_info()
+        assert info["rows"] == 8192 and info["form"] == ("nested_dissection" if form == "nd" else "block_tridiagonal")
+        x = np.zeros_like(b)
+        h, rc = A.solve("pcg", b, x)
+        assert rc == 0
+        hs.append(h)
+        xs.append(x)
+        A.close()
+    assert len(hs[0]) == len(hs[1])
+    assert np.all(np.abs(hs[0] - hs[1]) <= hist_tolerance(hs[0]) * hs[0])
+    assert np.linalg.norm(xs[0] - xs[1]) <= 1e-9 * np.linalg.norm(xs[0])
+
+
+def test_refused_coarsest_level_extends_the_hierarchy():
+    """with the default parameters a coarsest level the direct solver cannot take (here: a random sparsity pattern
+    without separators, 12 500 rows after 6 levels) must not fail the setup: the hierarchy is extended by the reference's own
+    coarsening rule, as it was before the reference's level policy became the default."""
+    rp, ci, v = problems.random_spd(400000, 9, seed=5)
+    b = np.ones(len(rp) - 1)
+    for form in ("nd", "bt"):
+        A = sa.sp_matrix_mg(rp, ci, v).set_coarse_form(form).setup(sa.default_params(**QUIET, dense_limit=4000))
+        info = A.coarse_info()
+        assert A.nlevels > 6 and info["dense"] and info["extended"], (A.nlevels, info)
+        x = np.zeros_like(b)
+        h, rc = A.solve("pcg", b, x)
+        S = sp.csr_matrix((v, ci, rp))
+        assert rc == 0 and np.linalg.norm(b - S @ x) <= 1.0001e-8
+        A.close()
+
+
 def test_dense_and_block_form_agree():
-    """Same hierarchy, coarsest level once through the dense inverse, once through the block factors."""
+    """Same hierarchy, coarsest level once through the dense inverse, once through the device factors."""
     rp, ci, v = problems.poisson3d(40)
     b = np.ones(len(rp) - 1)
     hs, xs = [], []
@@ -108,13 +189,15 @@ def test_dense_and_block_form_agree():
 
 
 def test_too_wide_operator_is_refused():
-    """A random sparsity pattern has no band structure: the block form would need blocks beyond the
-    limit, and the setup must say so instead of building something huge."""
+    """A random sparsity pattern has neither band structure nor separators: when the caller's parameters leave no room to extend
+    the hierarchy (one level forced) the setup must say so instead of building something huge."""
     rp, ci, v = problems.random_spd(20000, 9, seed=5)
-    A = sa.sp_matrix_mg(rp, ci, v)
-    with pytest.raises(sa.SparshError) as e:
-        A.setup(sa.default_params(**QUIET, **ONE_LEVEL))
-    assert "too wide" in str(e.value)
+    for form, msg in (("bt", "too wide"), ("nd", "no usable separator")):
+        A = sa.sp_matrix_mg(rp, ci, v).set_coarse_form(form)
+        with pytest.raises(sa.SparshError) as e:
+            A.setup(sa.default_params(**QUIET, **ONE_LEVEL))
+        assert msg in str(e.value), str(e.value)
+        A.close()
 
 
 def _hist_ok(h, ref):
@@ -138,7 +221,7 @@ def test_reference_level_policy_100cubed(p100, golden):
     assert [A.level_info(l)["nrow"] for l in range(A.nlevels)] == g["levels_nrow"]       # 6 levels, 31 250-row coarsest
     assert [A.level_info(l)["nnz"] for l in range(A.nlevels)] == g["levels_nnz_stored"]
     info = A.coarse_info()
-    assert info["rows"] == 31250 and not info["dense"] and not info["extended"]
+    assert info["rows"] == 31250 and not info["dense"] and not info["extended"] and info["form"] == "nested_dissection"
 
 
 def test_golden_100cubed_pcg_on_device(p100, golden):

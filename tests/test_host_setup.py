@@ -216,6 +216,44 @@ def test_block_tridiagonal_plan_on_host(tmp_path_factory, args):
     assert "relerr" in r.stdout
 
 
+def _nd_plan_check(tmp_path_factory, args, env=None):
+    import subprocess
+
+    d = tmp_path_factory.getbasetemp() / "ndplan"
+    d.mkdir(exist_ok=True)
+    exe = d / "nd_plan_check"
+    if not exe.exists():
+        csrc = os.path.join(ROOT, "sparsh_amg_amd", "csrc")
+        cmd = ["g++", "-std=c++17", "-O2", f"-I{csrc}", os.path.join(ROOT, "tests", "cpp", "nd_plan_check.cpp"), os.path.join(csrc, "nd_plan.cpp"), "-o", str(exe)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe), *args], capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-500:])
+    return r.stdout
+
+
+@pytest.mark.parametrize("args", [
+    ("grid3", "10", "32"), ("grid3", "16", "64"), ("grid3", "12", "32", "0"), ("grid2", "40", "32"), ("grid2", "100", "64"),
+    ("rand", "3000", "32"), ("blocks", "2000", "16"), ("grid3", "3", "64"), ("grid2", "7", "4"), ("box", "9006020", "16", "48"),
+])
+def test_nested_dissection_plan_solves_on_the_host(tmp_path_factory, args):
+    """csrc/nd_plan.cpp without a GPU: ordering, update sets, front positions, extend-add maps, forward segments and backward
+    gather lists run through a plain host emulation of the device kernels' algebra (tests/cpp/nd_plan_check.cpp): the multifrontal
+    factorisation must solve A x = b to 1e-12 on grids, a box, random nonsymmetric patterns and a matrix made of disconnected pieces."""
+    out = _nd_plan_check(tmp_path_factory, list(args))
+    assert "relerr" in out
+
+
+def test_nested_dissection_plan_of_the_100cubed_coarsest_level(tmp_path_factory):
+    """Shape of the plan for a 25 x 25 x 50 grid operator (the 31 250-row coarsest level of 100^3 has this graph up to the
+    aggregation pattern): the point of the form is few dependent launches and small factors against the 31-step chain and the
+    260 MB of the block-tridiagonal form."""
+    out = _nd_plan_check(tmp_path_factory, ["box", "25025050", "64"], {"ND_PLAN_ONLY": "1"})
+    head = out.splitlines()[0].split()
+    levels, factor_mb = int(head[head.index("levels") + 1]), float(head[head.index("factor_MB") + 1])
+    assert levels <= 9 and factor_mb < 140.0, out
+
+
 def test_reference_level_policy_is_the_default():
     """Up to coarse_limit (40 000) rows left over, max_levels = 6 is honoured exactly as the reference does
     (src/AMG_phases.cpp:51,77): 100^3 -> 6 levels with a 31 250-row coarsest level for the direct solver."""

@@ -25,6 +25,9 @@ def run(name, rp, ci, v, methods, rhs="ones", **params):
     A = sa.sp_matrix_mg(rp, ci, v)
     if os.environ.get("SPARSH_COARSE_BLOCK"):  # A/B of the block-tridiagonal coarse solver's block size
         A.set_coarse_block(int(os.environ["SPARSH_COARSE_BLOCK"]))
+    if os.environ.get("SPARSH_COARSE_FORM"):   # "nd[,leaf[,merge_rows]]" or "bt": A/B of the two device factorisations
+        f = os.environ["SPARSH_COARSE_FORM"].split(",")
+        A.set_coarse_form(f[0], int(f[1]) if len(f) > 1 else 0, int(f[2]) if len(f) > 2 else -1)
     A.setup(sa.default_params(print_setup=0, print_solve=0, **params))
     out["levels"] = [A.level_info(l)["nrow"] for l in range(A.nlevels)]
     out["level_kernels"] = [A.level_kernel(l) for l in range(A.nlevels - 1)]
