@@ -268,21 +268,40 @@ def main():
 
     # dominant kernel: fused Jacobi sweep on the finest level, timed by HIP events on the
     # engine's stream inside the timed region (sparsh_profile)
-    def layout_bytes(H, nrow, nnz_l):
-        """Bytes the layout a handle launches on level 0 has to move per fused sweep: the value (and index)
-        streams it really reads + b, x (gathered once), x_new; the mirrors take d_i out of the value stream."""
-        fmt, stored = H.level_format(0)
-        _, _, meta = H.level_layout(0)
+    def layout_bytes(H, nrow, nnz_l, level=0, vectors=3):
+        """Bytes the layout a handle launches on a level has to move per SpMV-type launch: the value (and index) streams it
+        really reads + `vectors` n-vectors (fused sweep: b, x gathered once, x_new = 3; residual 3; plain SpMV 2); the mirrors
+        take d_i out of the value stream."""
+        fmt, stored = H.level_format(level)
+        _, _, meta = H.level_layout(level)
+        vec = 8 * vectors * nrow
         if fmt == 3:
-            return 8 * stored + meta + 24 * nrow
+            return 8 * stored + meta + vec
         if fmt == 2:
-            return 12 * stored + 4 * nrow + 24 * nrow
-        if H.level_kernel(0) == "csr_rowlane_kernel":
-            return 12 * nnz_l + 28 * nrow  # CSR-stream with the diagonal picked out of the value stream: diag[] is not read
-        if H.level_kernel(0) == "csr_rowlane16_kernel":
-            b16, nb = H.level_index16(0)  # 16-bit delta-coded column indices (+ 4 B of base per row block); blocks that keep col[] priced at 12 B
-            return int(round((10 * b16 + 12 * (nb - b16)) / max(nb, 1) * nnz_l)) + 4 * nb + 28 * nrow
-        return 12 * nnz_l + 36 * nrow  # CSR-stream: rowptr, col, val, d, b, x, x_new = the SURVEY 8d model itself
+            return 12 * stored + 4 * nrow + vec
+        if H.level_kernel(level) == "csr_rowlane_kernel":
+            return 12 * nnz_l + 4 * nrow + vec  # CSR-stream with the diagonal picked out of the value stream: diag[] is not read
+        if H.level_kernel(level) == "csr_rowlane16_kernel":
+            b16, nb = H.level_index16(level)  # 16-bit delta-coded column indices (+ 4 B of base per row block); blocks that keep col[] priced at 12 B
+            return int(round((10 * b16 + 12 * (nb - b16)) / max(nb, 1) * nnz_l)) + 4 * nb + 4 * nrow + vec
+        return 12 * nnz_l + 12 * nrow + vec  # CSR-stream: rowptr, col, val, d + the vectors = the SURVEY 8d model itself
+
+    def iteration_layout_bytes(H):
+        """Bytes one AMG-PCG iteration has to move with the layouts this handle launches (SURVEY 8d metric (ii), priced per
+        launch as roofline.bytes_per_launch is): per level l < L 2 nu - 1 fused sweeps + the zero-guess sweep (x = w b / d: 3
+        vectors; on level 0 it rides in cg_update) + residual + aggregation restrict / prolong, the coarsest solve, and on
+        level 0 the Krylov step: SpMV with the p.Ap dot, cg_update (p, Ap, x, r, d read; x, r, z written), p update."""
+        total = 0
+        for l, (nl, nnzl, pn, pnnz) in enumerate(levels[:-1]):
+            ncl = levels[l + 1][0]
+            total += (2 * sweeps - 1) * layout_bytes(H, nl, nnzl, l, 3) + layout_bytes(H, nl, nnzl, l, 3)
+            if l > 0:
+                total += 24 * nl
+            total += (4 * (ncl + 1) + 4 * pnnz + 8 * nl + 8 * ncl) + (4 * nl + 8 * ncl + 16 * nl)
+        total += coarse["bytes"] + 16 * levels[-1][0]
+        n0, nnz0 = levels[0][0], levels[0][1]
+        total += layout_bytes(H, n0, nnz0, 0, 2) + 64 * n0 + 24 * n0
+        return total
 
     def kernel_label(H):
         nt, remap = H.level_placement(0)
@@ -339,8 +358,12 @@ def main():
         try:
             t_spmv = A.bench_op("spmv", 0, 20)
             sp_bytes = 12 * pr["nnz"] + 20 * pr["nrow"]
-            spmv = {"us": round(t_spmv * 1e6, 2), "GBps": round(sp_bytes / t_spmv / 1e9, 1),
-                    "frac_of_8TBps": round(sp_bytes / t_spmv / 1e9 / HBM_PEAK_GBS, 4), "bytes_csr_model": sp_bytes,
+            sp_layout = layout_bytes(A, pr["nrow"], pr["nnz"], 0, 2)
+            spmv = {"us": round(t_spmv * 1e6, 2), "kernel": A.level_kernel(0), "bytes_per_launch": sp_layout,
+                    "GBps": round(sp_layout / t_spmv / 1e9, 1), "frac": round(sp_layout / t_spmv / 1e9 / HBM_PEAK_GBS, 4),
+                    "csr_model_bytes": sp_bytes, "csr_model_effective_GBps": round(sp_bytes / t_spmv / 1e9, 1),
+                    "note": "GBps / frac price the SpMV with the bytes the launched layout streams (value / index streams + x, y); csr_model_effective_GBps "
+                            "prices it with SURVEY 8d's 12 nnz + 20 n: an effective rate (above the HBM peak where the layout does not stream CSR), not a bandwidth",
                     "rows": pr["nrow"], "nnz": pr["nnz"]}
         except Exception as e:  # noqa: BLE001
             spmv = {"error": repr(e)}
@@ -417,6 +440,7 @@ def main():
     # roofline.traffic: HBM bytes per launch of the dominant kernel from PMC counters, collected in THIS run by
     # two child processes (separate FETCH_SIZE / WRITE_SIZE passes, MI355X_MICROARCH.md), same grid, same
     # kernel configuration; corrected with calibration kernels of known size run in the same child.
+    pmc_iteration = None
     if roof is not None and rank == 0 and world == 1 and mode == "single" and not args.no_pmc:
         import shutil
         import subprocess
@@ -432,7 +456,7 @@ def main():
             for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
                 log(f"PMC pass {ctr}")
                 cmd = [rocprof, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmpd, sub), "--",
-                       sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), "--run", "--grid", str(args.grid), "--layout", lay]
+                       sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), "--run", "--grid", str(args.grid), "--layout", lay, "--iters", "10"]
                 if kcfg:
                     cmd += ["--kcfg", kcfg]
                 if no_fold:
@@ -451,6 +475,7 @@ def main():
             roof["traffic_GBps"] = round(traffic / avg / 1e9, 1)
             roof["traffic_frac"] = round(traffic / avg / 1e9 / HBM_PEAK_GBS, 4)
             roof["traffic_over_layout_bytes"] = round(traffic / fmt_bytes, 3)
+            pmc_iteration = res.get("iteration")
             roof["traffic_how"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this run (tools/pmc_traffic.py): counter KiB -> bytes, "
                                    f"FETCH_SIZE x{res['fetch_correction']['8B_per_lane(axpby)']:.4f} from an axpby of known size in the same process")
             try:
@@ -466,6 +491,25 @@ def main():
             shutil.rmtree(tmpd, ignore_errors=True)
     elif roof is not None:
         roof["traffic_how"] = "not measured in this run (counter passes run at N=1 on rank 0 only, or were disabled)"
+
+    # SURVEY 8d metric (ii): HBM GB/s of the whole iteration -- on the bytes the launched layouts have to move, and on the bytes
+    # the PMC counters saw (the same child passes as roofline.traffic, 10 iterations between marker launches)
+    whole = None
+    if mode == "single" and world == 1:
+        lay_it = iteration_layout_bytes(A)
+        whole = {"layout_GB_per_iteration": round(lay_it / 1e9, 4), "layout_GBps": round(lay_it * its_per_s / 1e9, 1),
+                 "layout_frac": round(lay_it * its_per_s / 1e9 / HBM_PEAK_GBS, 4),
+                 "hbm_GB_per_iteration": None, "hbm_GBps": None, "hbm_frac": None,
+                 "note": "layout_* = bytes the launched layouts have to move per iteration (every SpMV-type launch priced like roofline.bytes_per_launch, "
+                         "+ transfer, Krylov and coarsest-solve bytes) x iterations/s; hbm_* = FETCH_SIZE + WRITE_SIZE summed over every dispatch of 10 "
+                         "iterations in the PMC child passes of this run x iterations/s (Infinity-Cache hits are counted by these counters); both <= 1 of 8 TB/s"}
+        if pmc_iteration:
+            hb = pmc_iteration["hbm_bytes_per_iteration"]
+            whole.update({"hbm_GB_per_iteration": round(hb / 1e9, 4), "hbm_GBps": round(hb * its_per_s / 1e9, 1),
+                          "hbm_frac": round(hb * its_per_s / 1e9 / HBM_PEAK_GBS, 4),
+                          "hbm_read_GB_per_iteration": round(pmc_iteration["hbm_read_bytes_per_iteration"] / 1e9, 4),
+                          "hbm_write_GB_per_iteration": round(pmc_iteration["hbm_write_bytes_per_iteration"] / 1e9, 4),
+                          "dispatches_per_iteration": pmc_iteration["dispatches_per_iteration"]})
 
     # multi-GPU diagnostics for tuning (collective calls, every rank): what one halo exchange, one
     # scalar all-reduce and the all-gather at the replication boundary cost on this node
@@ -567,7 +611,7 @@ def main():
 
     if True:
         line = {
-            "metric": "AMG-PCG solve iterations/sec (7-pt 3D Poisson, fp64) + HBM GB/s",
+            "metric": "AMG-PCG solve iterations/sec (7-pt 3D Poisson, fp64) + HBM GB/s (roofline: dominant kernel; config.whole_iteration: the iteration)",
             "value": round(its_per_s, 3),
             "unit": "iterations/s",
             "n_gpus": world,
@@ -597,9 +641,9 @@ def main():
                                      if bi[1] > 0 else "every rank ran the host setup itself")(A.setup_share_info())),
                 "placement_search": A.placement_info() if world == 1 else None,  # setup-time choice of the finest level's sweep buffers
                 "multi_gpu_parity": parity,
-                "algorithmic_GB_per_iteration": round(it_bytes / 1e9, 3),
-                "solve_GBps": round(it_bytes * its_per_s / 1e9, 1),
-                "solve_frac_of_8TBps": round(it_bytes * its_per_s / 1e9 / HBM_PEAK_GBS, 4),
+                "whole_iteration": whole,
+                "csr_model_GB_per_iteration": round(it_bytes / 1e9, 3),
+                "csr_model_effective_GBps": round(it_bytes * its_per_s / 1e9, 1),
                 "spmv_finest_level": spmv,
                 "residual_after_timed_steps": float(last_hist[-1]),
                 "solve_restarted_every": RESTART,
@@ -678,8 +722,7 @@ def main():
             if good and el_b < elapsed:
                 line["value"] = round(args.steps / el_b, 3)
                 line["ms_per_step"] = round(el_b / args.steps * 1e3, 4)
-                line["config"]["solve_GBps"] = round(it_bytes * args.steps / el_b / 1e9, 1)
-                line["config"]["solve_frac_of_8TBps"] = round(it_bytes * args.steps / el_b / 1e9 / HBM_PEAK_GBS, 4)
+                line["config"]["csr_model_effective_GBps"] = round(it_bytes * args.steps / el_b / 1e9, 1)
                 line["config"]["parallelism"] += "; halo exchange overlapped with the interior slices on a second stream"
         except Exception as e:  # noqa: BLE001
             log(f"overlap phase failed: {e!r}")

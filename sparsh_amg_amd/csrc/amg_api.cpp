@@ -11,6 +11,7 @@
 #include <cctype>
 #include <cstring>
 #include <fstream>
+#include <numeric>
 #include <iostream>
 #include <sstream>
 #include <string>
@@ -132,31 +133,46 @@ void sp_matrix_mg::scale_system(double *&b)
 
 // ------------------------------------------------------------------------------ readers
 
+// The reference's native text format (src/AMG_file_read.cpp:39-72): "nrow ncol nnz", then nnz triplets "row col val"
+// (0-based, sorted by row), and a second file "nrow" + one right-hand-side value per line.  Read here into
+// triplet vectors first, then turned into CSR by a count pass and a prefix sum; triplets that are not sorted by
+// row are placed correctly too (a stable counting sort), where the reference silently builds a wrong matrix.
 void readcoo(char *matrixfile, char *rhsfile, sp_matrix_mg *&A, double *&b)
 {
-    std::ifstream in(matrixfile);
-    if (!in) {
+    A = nullptr;
+    b = nullptr;
+    std::ifstream min(matrixfile);
+    if (!min) {
         std::cout << "Cannot open " << matrixfile << std::endl;
-        A = nullptr;
-        b = nullptr;
         return;
     }
-    int nrow = 0, ncol = 0, nnnz = 0;
-    in >> nrow >> ncol >> nnnz;
-    A = new sp_matrix_mg(nrow, ncol, nnnz);
-    b = new double[(size_t)nrow]();
-    for (int i = 0; i < nnnz; i++) {
-        int k = 0;
-        in >> k >> A->colindex[i] >> A->val[i];
-        A->rowptr[k + 1]++;  // entries must arrive sorted by row (as in the reference)
+    int nrow = 0, ncol = 0, nnz = 0;
+    min >> nrow >> ncol >> nnz;
+    if (!min || nrow < 0 || ncol < 0 || nnz < 0) {
+        std::cout << matrixfile << ": bad header" << std::endl;
+        return;
     }
-    in.close();
+    std::vector<int> trow((size_t)nnz), tcol((size_t)nnz);
+    std::vector<double> tval((size_t)nnz);
+    int got = 0;
+    while (got < nnz && (min >> trow[got] >> tcol[got] >> tval[got])) ++got;
+    if (got != nnz) std::cout << matrixfile << ": " << got << " of " << nnz << " entries read" << std::endl;
+    A = new sp_matrix_mg(nrow, ncol, nnz);  // zero-filled (rowptr included)
+    for (int e = 0; e < got; ++e)
+        if (trow[e] >= 0 && trow[e] < nrow) ++A->rowptr[trow[e] + 1];
+    std::partial_sum(A->rowptr, A->rowptr + nrow + 1, A->rowptr);
+    std::vector<int> next(A->rowptr, A->rowptr + nrow);
+    for (int e = 0; e < got; ++e) {
+        if (trow[e] < 0 || trow[e] >= nrow) continue;
+        const int at = next[trow[e]]++;
+        A->colindex[at] = tcol[e];
+        A->val[at] = tval[e];
+    }
+    b = new double[(size_t)nrow]();
     std::ifstream rin(rhsfile);
-    int k = 0;
-    rin >> k;
-    for (int i = 0; i < nrow; i++) {
-        rin >> b[i];
-        A->rowptr[i + 1] += A->rowptr[i];
+    int declared = 0;
+    rin >> declared;
+    for (int i = 0; i < nrow && (rin >> b[i]); ++i) {
     }
 }
 

@@ -201,6 +201,7 @@ int sparsh_set_kernel_config(sparsh_handle h, int kind, int vec, int nt, int rem
     c.nt = nt > 0;
     c.remap = remap < 0 ? 0 : remap;
     c.auto_policy = (nt < 0 || remap < 0);
+    h->eng->config_changed();
     return SPARSH_OK;
 }
 
@@ -282,6 +283,7 @@ int sparsh_set_tile(sparsh_handle h, int enable)
 {
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
     h->eng->kernel_cfg().tile = enable != 0;
+    h->eng->config_changed();
     return SPARSH_OK;
 }
 
@@ -297,6 +299,7 @@ int sparsh_set_const_slots(sparsh_handle h, int enable)
 {
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
     h->eng->kernel_cfg().const_slots = enable != 0;
+    h->eng->config_changed();
     return SPARSH_OK;
 }
 
@@ -392,6 +395,7 @@ int sparsh_set_fused_zero_sweep(sparsh_handle h, int enable)
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
     h->eng->kernel_cfg().fuse_cg_zero = enable != 0;
     h->eng->kernel_cfg().cg_nt = enable == 2;
+    h->eng->config_changed();
     return SPARSH_OK;
 }
 
@@ -400,6 +404,7 @@ int sparsh_set_alternate_sweeps(sparsh_handle h, int enable)
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
     if (enable < 0 || enable > 2) return fail(SPARSH_EINVAL, "mode must be 0 (never), 1 (where a sweep streams more than the Infinity Cache holds) or 2 (always)");
     h->eng->kernel_cfg().alt_dir = enable;
+    h->eng->config_changed();
     return SPARSH_OK;
 }
 
@@ -408,6 +413,7 @@ int sparsh_set_index_compression(sparsh_handle h, int mode)
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
     if (mode < 0 || mode > 2) return fail(SPARSH_EINVAL, "mode must be 0 (off), 1 (operators that stream from HBM through the CSR-stream kernel) or 2 (every operator)");
     h->eng->kernel_cfg().idx16 = mode;
+    h->eng->config_changed();
     return SPARSH_OK;
 }
 

@@ -514,6 +514,9 @@ int Engine::setup_host_shared(const sparsh_params &p)
 {
     const int me = comm_->rank;
     const double t0 = omp_get_wtime();
+    // every rank, not only the one that builds: the OpenMP regions of the local extraction and the uploads that follow must not
+    // oversubscribe the host with (ranks x all cores) threads
+    omp_set_num_threads(p.host_threads > 0 ? p.host_threads : effective_cpus());
     std::vector<char> image;
     int rc0 = SPARSH_OK;
     std::string err0;
@@ -546,7 +549,30 @@ int Engine::setup_host_shared(const sparsh_params &p)
     // the image travels through one device staging buffer, chunk by chunk
     const size_t chunk = std::min<size_t>(total, (size_t)256 << 20);
     char *stage = nullptr;
-    if (chunk > 0 && !check(hipMalloc(reinterpret_cast<void **>(&stage), chunk), "hipMalloc")) return SPARSH_ENODEV;
+    // A rank whose staging buffer cannot be allocated must not leave the others waiting in the broadcasts below: the ranks
+    // agree on the outcome first (sum of failure flags), then either all proceed or all return the error.
+    {
+        const bool mine = chunk == 0 || hipMalloc(reinterpret_cast<void **>(&stage), chunk) == hipSuccess;
+        double *flag = nullptr;
+        if (!check(hipMalloc(reinterpret_cast<void **>(&flag), sizeof(double)), "hipMalloc")) {
+            if (stage) (void)hipFree(stage);
+            return SPARSH_ENODEV;
+        }
+        double f = mine ? 0.0 : 1.0;
+        bool okf = check(hipMemcpyAsync(flag, &f, sizeof(double), hipMemcpyHostToDevice, st_), "hipMemcpy") && comm_->allreduce_sum(flag, 1, st_) &&
+                   check(hipMemcpyAsync(&f, flag, sizeof(double), hipMemcpyDeviceToHost, st_), "hipMemcpy") && check(hipStreamSynchronize(st_), "hipStreamSynchronize");
+        (void)hipFree(flag);
+        if (!okf || f != 0.0) {
+            if (stage) (void)hipFree(stage);
+            if (!okf) {
+                if (error.empty()) error = "agreement on the hierarchy staging buffers failed: " + comm_->error;
+                return SPARSH_ECOMM;
+            }
+            error = mine ? "another rank could not allocate its staging buffer for the hierarchy broadcast"
+                         : "hipMalloc of the " + std::to_string(chunk >> 20) + " MB staging buffer for the hierarchy broadcast failed";
+            return SPARSH_ENODEV;
+        }
+    }
     for (size_t off = 0; good && off < total; off += chunk) {
         const size_t nb = std::min(chunk, total - off);
         if (me == 0) good = check(hipMemcpyAsync(stage, image.data() + off, nb, hipMemcpyHostToDevice, st_), "hipMemcpy");

@@ -96,8 +96,11 @@ public:
     CoarseSolver &coarse_mut() { return coarse_; }
     const sparsh_params &params() const { return prm_; }
     // kernel-family / layout choices of THIS handle (const_slots is read when the layouts are built)
+    // (mutable access is for the C ABI's setters, which call config_changed() afterwards)
     KernelConfig &kernel_cfg() { return cfg_; }
     const KernelConfig &kernel_cfg() const { return cfg_; }
+    // a captured hipGraph of the iteration replays the kernels of the configuration it was captured under: drop it
+    void config_changed() { drop_graph(); }
     // average seconds of one communication step alone (collective: every rank calls it): what = 0 halo
     // exchange of level `level`'s operator, 1 the 16-byte all-reduce of the fused scalars, 2 the
     // all-gather at the partitioned -> replicated boundary.  -1 when the step does not exist.

@@ -7,8 +7,9 @@
 //   invert       D^-1 of the pivot block, Gauss-Jordan with partial pivoting inside the block (one workgroup per node;
 //                pivot blocks above kNdSmallPivot rows go through the whole-chip inversion of coarse_kernels.hip)
 //   gemm         -D^-1 F12 -> B_k ; F21 D^-1 -> Lh_k ; F22 += F21 (-D^-1 F12)      (batched 64 x 64 tiles, fp64)
-// Solve (2 * levels launches): c = b[perm]; per level upwards c[r] -= sum over segments Lh.c ; per level downwards
-// x[P_k] = B_k [c[P_k]; x[U_k]], scattered back to the caller's numbering.  No atomics: every sum has a fixed order.
+// Solve (2 * levels - 1 launches): per level upwards c[r] = b[perm r] - (row of Lh laid out per target row) . c ; per level
+// downwards x[P_k] = B_k [c[P_k]; x[U_k]], scattered back to the caller's numbering; both through the same gathered-dot
+// kernel.  No atomics: every sum has a fixed order.
 #include <hip/hip_runtime.h>
 
 #include "nd_solver.hpp"
@@ -210,97 +211,64 @@ __global__ __launch_bounds__(kNB) void nd_gemm_kernel(const NdGemm *__restrict__
     }
 }
 
-__global__ __launch_bounds__(kNB) void nd_permute_kernel(int n, const int *__restrict__ perm, const double *__restrict__ b, double *__restrict__ c)
+// Lh rows (row-major per source node, as the products leave them) -> the per-target-row layout of the forward pass:
+// one wave per segment copies p numbers
+__global__ __launch_bounds__(kNB) void nd_repack_kernel(long long nseg, const NdSegment *__restrict__ segs, const double *__restrict__ Lh,
+                                                        double *__restrict__ Lf)
 {
-    const int i = blockIdx.x * kNB + threadIdx.x;
-    if (i < n) c[i] = b[perm[i]];
-}
-
-// forward, one tree level: c[r] -= sum over the row's segments of Lh[moff .. moff + p) . c[first .. first + p)
-// WIDE = false: one wave per row; true: one workgroup per row (long rows of the top separators)
-template <bool WIDE>
-__global__ __launch_bounds__(kNB) void nd_forward_kernel(const int *__restrict__ rows, int nrows, const int *__restrict__ seg_ptr,
-                                                         const NdSegment *__restrict__ segs, const double *__restrict__ Lm, double *__restrict__ c)
-{
-    __shared__ double part[kNB / 64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int q = WIDE ? blockIdx.x : blockIdx.x * (kNB / 64) + wv;
-    if (q >= nrows) return;
-    const int r = rows[q];
-    const int s0 = seg_ptr[r], s1 = seg_ptr[r + 1];
-    const int tid = WIDE ? threadIdx.x : lane;
-    constexpr int STR = WIDE ? kNB : 64;
-    double a0 = 0.0, a1 = 0.0;
-    int s = s0;
-    for (; s + 1 < s1; s += 2) {  // two segments at a time: their loads are independent
-        const NdSegment g0 = segs[s], g1 = segs[s + 1];
-        const double *__restrict__ m0 = Lm + g0.moff, *__restrict__ m1 = Lm + g1.moff;
-        const double *__restrict__ v0 = c + g0.first, *__restrict__ v1 = c + g1.first;
-        const int pm = g0.p > g1.p ? g0.p : g1.p;
-        for (int t = tid; t < pm; t += STR) {
-            const double x0 = t < g0.p ? m0[t] * v0[t] : 0.0;
-            const double x1 = t < g1.p ? m1[t] * v1[t] : 0.0;
-            a0 += x0;
-            a1 += x1;
-        }
-    }
-    if (s < s1) {
-        const NdSegment g0 = segs[s];
-        const double *__restrict__ m0 = Lm + g0.moff;
-        const double *__restrict__ v0 = c + g0.first;
-        for (int t = tid; t < g0.p; t += STR) a0 += m0[t] * v0[t];
-    }
-    double acc = nd_wsum(a0 + a1);
-    if (WIDE) {
-        if (lane == 0) part[wv] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0) c[r] -= (part[0] + part[1]) + (part[2] + part[3]);
-    } else if (lane == 0) {
-        c[r] -= acc;
+    const int lane = threadIdx.x & 63;
+    for (long long s = (long long)blockIdx.x * (kNB / 64) + (threadIdx.x >> 6); s < nseg; s += (long long)gridDim.x * (kNB / 64)) {
+        const NdSegment g = segs[s];
+        for (int t = lane; t < g.p; t += 64) Lf[g.dst + t] = Lh[g.moff + t];
     }
 }
 
-// backward, one tree level: x[r] = B_k[row] . [c[P_k]; x[U_k]] through the node's gather list (w = [c | x], both in the new
-// numbering), written to w and, through perm, to the caller's vector
-template <bool WIDE>
-__global__ __launch_bounds__(kNB) void nd_backward_kernel(const int *__restrict__ rows, const int *__restrict__ rnode, int nrows, int n,
-                                                          const NdDevNode *__restrict__ nodes, const int *__restrict__ idx,
-                                                          const double *__restrict__ Bm, double *__restrict__ w, const int *__restrict__ perm,
-                                                          double *__restrict__ x)
+// One pass of a solve over the rows of one tree level:  dot = sum_t M[moff + t] * vec[idx[ioff + t]],  vec = [c | x | b]
+// (w holds c and x in the new numbering, b is the caller's vector in its own numbering).
+//   FWD:  c[out] = b[bsrc] - dot            BWD:  x[out] = dot, also scattered to the caller's x[bsrc]
+// The first nwide rows are long: one workgroup each; the others one wave each, four to a workgroup.  All loads of a
+// row's first 8 (x 64 or x 256) elements are issued before the first use: record -> {M, idx} -> vec is the whole
+// dependent chain of a launch.
+template <bool FWD>
+__global__ __launch_bounds__(kNB) void nd_gdot_kernel(const NdRow *__restrict__ rows, int nrows, int nwide, int n, const double *__restrict__ M,
+                                                      const int *__restrict__ idx, double *__restrict__ w, const double *__restrict__ b,
+                                                      double *__restrict__ x)
 {
     __shared__ double part[kNB / 64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int q = WIDE ? blockIdx.x : blockIdx.x * (kNB / 64) + wv;
-    if (q >= nrows) return;
-    const int r = rows[q];
-    const NdDevNode nd = nodes[rnode[q]];
-    const int len = nd.np + nd.nu;
-    const double *__restrict__ row = Bm + nd.boff + (size_t)(r - nd.first) * len;
-    const int *__restrict__ ix = idx + nd.ioff;
-    const int tid = WIDE ? threadIdx.x : lane;
-    constexpr int STR = WIDE ? kNB : 64;
-    constexpr int U = 4;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool wide = (int)blockIdx.x < nwide;
+    const int q = wide ? (int)blockIdx.x : nwide + ((int)blockIdx.x - nwide) * (kNB / 64) + wv;
+    if (q >= nrows) return;  // narrow tail only: a wide workgroup keeps all its waves
+    const NdRow R = rows[q];
+    const double *__restrict__ row = M + R.moff;
+    const int *__restrict__ ix = idx + R.ioff;
+    const int tid = wide ? (int)threadIdx.x : lane;
+    const int str = wide ? kNB : 64;
+    const int n2 = 2 * n;
+    double b0 = 0.0;
+    if (FWD && lane == 0) b0 = b[R.bsrc];
+    constexpr int U = 8;
     double acc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) acc[u] = 0.0;
-    for (int t0 = tid; t0 < len; t0 += U * STR) {
-        double m[U];
+    for (int t0 = tid; t0 < R.len; t0 += U * str) {
+        double m[U], v[U];
         int g[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int t = t0 + u * STR;
-            const bool on = t < len;
+            const int t = t0 + u * str;
+            const bool on = t < R.len;
             m[u] = on ? row[t] : 0.0;
             g[u] = on ? ix[t] : 0;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int t = t0 + u * STR;
-            acc[u] += t < len ? m[u] * w[g[u]] : 0.0;
-        }
+        for (int u = 0; u < U; ++u) v[u] = g[u] < n2 ? w[g[u]] : b[g[u] - n2];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] += (t0 + u * str < R.len) ? m[u] * v[u] : 0.0;
     }
-    double a = nd_wsum((acc[0] + acc[1]) + (acc[2] + acc[3]));
-    if (WIDE) {
+    double a = nd_wsum(((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7])));
+    if (wide) {
         if (lane == 0) part[wv] = a;
         __syncthreads();
         a = (part[0] + part[1]) + (part[2] + part[3]);
@@ -308,8 +276,12 @@ __global__ __launch_bounds__(kNB) void nd_backward_kernel(const int *__restrict_
     } else if (lane != 0) {
         return;
     }
-    w[n + r] = a;
-    x[perm[r]] = a;
+    if (FWD) {
+        w[R.out] = b0 - a;
+    } else {
+        w[n + R.out] = a;
+        x[R.bsrc] = a;
+    }
 }
 
 }  // namespace
@@ -346,29 +318,23 @@ void nd_launch_gemm(const NdGemm *problems, const int *tiles, int ntiles, hipStr
     hipLaunchKernelGGL(nd_gemm_kernel, dim3(ntiles), dim3(kNB), 0, st, problems, tiles);
 }
 
-void nd_launch_permute(int n, const int *perm, const double *b, double *c, hipStream_t st)
+void nd_launch_repack(long long nseg, const NdSegment *segs, const double *Lh, double *Lf, hipStream_t st)
 {
-    hipLaunchKernelGGL(nd_permute_kernel, dim3((n + kNB - 1) / kNB), dim3(kNB), 0, st, n, perm, b, c);
+    if (nseg <= 0) return;
+    long long g = (nseg + kNB / 64 - 1) / (kNB / 64);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(nd_repack_kernel, dim3((unsigned)g), dim3(kNB), 0, st, nseg, segs, Lh, Lf);
 }
 
-void nd_launch_forward(const int *rows, int nrows, bool wide, const int *seg_ptr, const NdSegment *segs, const double *Lm, double *c, hipStream_t st)
+void nd_launch_pass(bool forward, const NdRow *rows, int nrows, int nwide, int n, const double *M, const int *idx, double *w, const double *b, double *x,
+                    hipStream_t st)
 {
     if (nrows <= 0) return;
-    if (wide)
-        hipLaunchKernelGGL(nd_forward_kernel<true>, dim3(nrows), dim3(kNB), 0, st, rows, nrows, seg_ptr, segs, Lm, c);
+    const int grid = nwide + (nrows - nwide + kNB / 64 - 1) / (kNB / 64);
+    if (forward)
+        hipLaunchKernelGGL(nd_gdot_kernel<true>, dim3(grid), dim3(kNB), 0, st, rows, nrows, nwide, n, M, idx, w, b, x);
     else
-        hipLaunchKernelGGL(nd_forward_kernel<false>, dim3((nrows + kNB / 64 - 1) / (kNB / 64)), dim3(kNB), 0, st, rows, nrows, seg_ptr, segs, Lm, c);
-}
-
-void nd_launch_backward(const int *rows, const int *rnode, int nrows, bool wide, int n, const NdDevNode *nodes, const int *idx, const double *Bm,
-                        double *w, const int *perm, double *x, hipStream_t st)
-{
-    if (nrows <= 0) return;
-    if (wide)
-        hipLaunchKernelGGL(nd_backward_kernel<true>, dim3(nrows), dim3(kNB), 0, st, rows, rnode, nrows, n, nodes, idx, Bm, w, perm, x);
-    else
-        hipLaunchKernelGGL(nd_backward_kernel<false>, dim3((nrows + kNB / 64 - 1) / (kNB / 64)), dim3(kNB), 0, st, rows, rnode, nrows, n, nodes, idx, Bm, w,
-                           perm, x);
+        hipLaunchKernelGGL(nd_gdot_kernel<false>, dim3(grid), dim3(kNB), 0, st, rows, nrows, nwide, n, M, idx, w, b, x);
 }
 
 }  // namespace sparsh

@@ -449,7 +449,62 @@ bool nd_make_plan(const HostCsr &A, const NdParams &prm, NdPlan &P, std::string 
             const NdNode &nd = P.nodes[k];
             for (int i = 0; i < nd.nu; ++i) {
                 const int r = P.upd_idx[nd.upd + i];
-                P.segs[pos[r]++] = NdSegment{(long long)(nd.loff + (size_t)i * nd.np), nd.first, nd.np};
+                P.segs[pos[r]++] = NdSegment{(long long)(nd.loff + (size_t)i * nd.np), 0, nd.first, nd.np};
+            }
+        }
+        // per-target-row layout and the vector index of each of its elements: a source row of a leaf reads the caller's
+        // right-hand side directly (index space [c | x | b], see nd_plan.hpp)
+        P.fwd_ptr.assign((size_t)n + 1, 0);
+        for (int r = 0; r < n; ++r) {
+            long long t = 0;
+            for (int s2 = P.seg_ptr[r]; s2 < P.seg_ptr[r + 1]; ++s2) {
+                P.segs[s2].dst = P.fwd_ptr[r] + t;
+                t += P.segs[s2].p;
+            }
+            P.fwd_ptr[r + 1] = P.fwd_ptr[r] + t;
+        }
+        if ((size_t)P.fwd_ptr[n] != P.l_doubles) {
+            err = "nested dissection: internal error (forward layout does not match the factor size)";
+            return false;
+        }
+        P.fidx.resize(P.l_doubles);
+        for (const NdSegment &g2 : P.segs) {
+            const bool leaf_src = P.nodes[P.node_of_row[g2.first]].level == 0;
+            for (int t = 0; t < g2.p; ++t) P.fidx[(size_t)g2.dst + t] = leaf_src ? 2 * n + P.perm[g2.first + t] : g2.first + t;
+        }
+    }
+    // ---- backward gather lists and the row records of both passes, level by level (long rows first)
+    {
+        P.bidx.resize(P.idx_ints);
+        for (int k = 0; k < nn; ++k) {
+            const NdNode &nd = P.nodes[k];
+            int *ix = P.bidx.data() + nd.ioff;
+            for (int t = 0; t < nd.np; ++t) ix[t] = nd.level == 0 ? 2 * n + P.perm[nd.first + t] : nd.first + t;
+            for (int i = 0; i < nd.nu; ++i) ix[nd.np + i] = n + P.upd_idx[nd.upd + i];
+        }
+        P.fwd.assign((size_t)P.nlevels, NdPass());
+        P.bwd.assign((size_t)P.nlevels, NdPass());
+        for (int l = 0; l < P.nlevels; ++l) {
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass == 0 && l == 0) continue;
+                NdPass &ps = pass ? P.bwd[l] : P.fwd[l];
+                std::vector<NdRow> narrow;
+                for (int k : P.level_nodes[l]) {
+                    const NdNode &nd = P.nodes[k];
+                    for (int q = 0; q < nd.np; ++q) {
+                        const int r = nd.first + q;
+                        NdRow R;
+                        if (pass == 0) {
+                            R = NdRow{P.fwd_ptr[r], P.fwd_ptr[r], (int)(P.fwd_ptr[r + 1] - P.fwd_ptr[r]), r, P.perm[r], 0};
+                        } else {
+                            const int len = nd.np + nd.nu;
+                            R = NdRow{(long long)(nd.boff + (size_t)q * len), (long long)nd.ioff, len, r, P.perm[r], 0};
+                        }
+                        (R.len > P.wide_len ? ps.rows : narrow).push_back(R);
+                    }
+                }
+                ps.nwide = (int)ps.rows.size();
+                ps.rows.insert(ps.rows.end(), narrow.begin(), narrow.end());
             }
         }
     }

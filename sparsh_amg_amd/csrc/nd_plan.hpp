@@ -11,8 +11,13 @@
 // explicitly, and what a solve needs is kept per node as dense row-major blocks
 //     Lh_k = F21 D_k^-1         (u x p)   forward:   c[U_k] -= Lh_k c[P_k]      (pulled by the target rows)
 //     B_k  = [D_k^-1 | -D_k^-1 F12]  (p x (p + u))   backward:  x[P_k] = B_k [c[P_k]; x[U_k]]
-// A solve is one launch per tree level up (forward) and one per level down (backward): 2 * height + 1 dependent
-// launches, against ~ n / bandwidth for the block-tridiagonal chain.
+// Both passes of a solve are then the same operation, row by row: a dot product of a contiguous row of numbers with
+// a vector gathered through an index list,  out = sum_t M[moff + t] * vec[idx[ioff + t]]  -- forward rows are the rows of
+// Lh re-laid per TARGET row (all contributions to c[r] side by side), backward rows are the rows of B_k.  `vec` is one
+// index space over three vectors: [0, n) c (forward result, new numbering), [n, 2n) x (new numbering), [2n, 3n) the
+// caller's right-hand side in ITS numbering (rows of leaves read it directly, so no permutation pass is needed).
+// A solve is one launch per tree level up (forward, levels >= 1) and one per level down (backward): 2 * height - 1
+// dependent launches, against ~ n / bandwidth for the block-tridiagonal chain.
 //
 // Pure host code, no HIP: tests/cpp/nd_plan_check.cpp runs the plan with a host emulation of the kernels.
 #pragma once
@@ -39,9 +44,23 @@ struct NdNode {
     size_t rel = 0;          // position of U_k[i] in the parent's front (rel_idx[rel + i])
 };
 
-struct NdSegment {           // one contribution to a forward target row: dot(Lh[moff .. moff + p), c[first .. first + p))
-    long long moff;
+struct NdSegment {           // one contribution to a forward target row: Lh[moff .. moff + p) (a row of Lh of the source node) times
+    long long moff;          // c[first .. first + p); `dst` = where that row goes in the per-target-row layout
+    long long dst;
     int first, p;
+};
+
+struct NdRow {               // one row of a solve pass: out = sum_t M[moff + t] * vec[idx[ioff + t]], t < len
+    long long moff, ioff;
+    int len;
+    int out;                 // new index of the row
+    int bsrc;                // the row's index in the caller's numbering (perm[out])
+    int pad;
+};
+
+struct NdPass {              // rows of one tree level for one pass; the first `nwide` rows are long (one workgroup each)
+    std::vector<NdRow> rows;
+    int nwide = 0;
 };
 
 struct NdPlan {
@@ -56,9 +75,15 @@ struct NdPlan {
     // entries of the permuted operator with their position in the fronts buffer (duplicates summed, sorted by position)
     std::vector<long long> a_dst;
     std::vector<double> a_val;
-    // forward: segments of every target row (CSR over new rows; rows of leaves have none)
+    // forward: segments of every target row (CSR over new rows; rows of leaves have none), the per-target-row layout they
+    // are re-laid into (fwd_ptr over new rows) and the vector index of every element of it
     std::vector<int> seg_ptr;
     std::vector<NdSegment> segs;
+    std::vector<long long> fwd_ptr;
+    std::vector<int> fidx;
+    std::vector<int> bidx;               // backward gather list of every node (np + nu ints at ioff)
+    std::vector<NdPass> fwd, bwd;        // per level (fwd[0] is empty)
+    int wide_len = 384;                  // rows longer than this get a whole workgroup
     size_t factor_bytes() const { return (b_doubles + l_doubles) * sizeof(double); }
     size_t front_bytes() const { return front_doubles * sizeof(double); }
 };

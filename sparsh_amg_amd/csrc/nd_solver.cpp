@@ -43,11 +43,10 @@ void NdSolver::release()
 {
     for (void *p : allocs_) (void)hipFree(p);
     allocs_.clear();
-    Bm_ = Lm_ = w_ = nullptr;
-    perm_ = idx_ = seg_ptr_ = nullptr;
-    segs_ = nullptr;
-    nodes_ = nullptr;
-    lev_.clear();
+    Bm_ = Lf_ = w_ = nullptr;
+    bidx_ = fidx_ = nullptr;
+    fwd_.clear();
+    bwd_.clear();
     n_ = nlevels_ = nnodes_ = leaf_ = max_np_ = launches_ = 0;
     factor_bytes_ = 0;
 }
@@ -82,9 +81,27 @@ bool NdSolver::setup(const HostCsr &A, const NdParams &prm, hipStream_t st, std:
         release();
         return false;
     };
-    // ---- persistent arrays
+    // ---- persistent arrays: the rows of both passes, their gather lists, the work vector
+    Bm_ = nd_alloc<double>(allocs_, P.b_doubles, err);
+    Lf_ = nd_alloc<double>(allocs_, P.l_doubles, err);
+    w_ = nd_alloc<double>(allocs_, (size_t)2 * n, err);
+    bidx_ = nd_upload(allocs_, P.bidx, err);
+    fidx_ = nd_upload(allocs_, P.fidx, err);
+    if (!(Bm_ && Lf_ && w_ && bidx_ && fidx_)) return fail();
+    fwd_.assign((size_t)P.nlevels, Pass());
+    bwd_.assign((size_t)P.nlevels, Pass());
+    for (int l = 0; l < P.nlevels; ++l)
+        for (int pass = 0; pass < 2; ++pass) {
+            const NdPass &src = pass ? P.bwd[l] : P.fwd[l];
+            Pass &dst = pass ? bwd_[l] : fwd_[l];
+            dst.nrows = (int)src.rows.size();
+            dst.nwide = src.nwide;
+            if (dst.nrows == 0) continue;
+            dst.rows = nd_upload(allocs_, src.rows, err);
+            if (!dst.rows) return fail();
+        }
+    // node descriptors of the factorisation kernels
     std::vector<NdDevNode> dn((size_t)nn);
-    std::vector<int> idx(P.idx_ints);
     for (int k = 0; k < nn; ++k) {
         const NdNode &nd = P.nodes[k];
         dn[k] = NdDevNode{(long long)nd.foff, (long long)nd.boff, (long long)nd.loff, (long long)nd.ioff, nd.first, nd.np, nd.nu, (int)nd.rel, nd.parent, 0};
@@ -93,44 +110,11 @@ bool NdSolver::setup(const HostCsr &A, const NdParams &prm, hipStream_t st, std:
             why = 1;
             return fail();
         }
-        int *ix = idx.data() + nd.ioff;
-        for (int t = 0; t < nd.np; ++t) ix[t] = nd.first + t;                              // c part of w
-        for (int i = 0; i < nd.nu; ++i) ix[nd.np + i] = n + P.upd_idx[nd.upd + i];          // x part of w
     }
-    nodes_ = nd_upload(allocs_, dn, err);
-    idx_ = nd_upload(allocs_, idx, err);
-    perm_ = nd_upload(allocs_, P.perm, err);
-    seg_ptr_ = nd_upload(allocs_, P.seg_ptr, err);
-    segs_ = nd_upload(allocs_, P.segs, err);
-    Bm_ = nd_alloc<double>(allocs_, P.b_doubles, err);
-    Lm_ = nd_alloc<double>(allocs_, P.l_doubles, err);
-    w_ = nd_alloc<double>(allocs_, (size_t)2 * n, err);
-    if (!(nodes_ && idx_ && perm_ && seg_ptr_ && segs_ && Bm_ && Lm_ && w_)) return fail();
-    // level row lists; a level whose rows are long gets one workgroup per row
-    lev_.assign((size_t)P.nlevels, Level());
-    for (int l = 0; l < P.nlevels; ++l) {
-        std::vector<int> rows, rnode;
-        long long fw = 0, bw = 0;
-        for (int k : P.level_nodes[l]) {
-            const NdNode &nd = P.nodes[k];
-            for (int r = 0; r < nd.np; ++r) {
-                rows.push_back(nd.first + r);
-                rnode.push_back(k);
-                long long t = 0;
-                for (int s = P.seg_ptr[nd.first + r]; s < P.seg_ptr[nd.first + r + 1]; ++s) t += P.segs[s].p;
-                fw = std::max(fw, t);
-            }
-            bw = std::max(bw, (long long)nd.np + nd.nu);
-        }
-        Level &L = lev_[l];
-        L.nrows = (int)rows.size();
-        L.rows = nd_upload(allocs_, rows, err);
-        L.rnode = nd_upload(allocs_, rnode, err);
-        if (!L.rows || !L.rnode) return fail();
-        // one wave streams 4 x 512 B per step: beyond ~2000 entries per row the whole workgroup takes the row
-        L.wide_fwd = fw > 2048 && L.nrows < 16384;
-        L.wide_bwd = bw > 2048 && L.nrows < 16384;
-    }
+    NdDevNode *nodes_ = nd_upload(tmp, dn, err);
+    double *Lm_ = nd_alloc<double>(tmp, P.l_doubles, err);  // Lh as the products leave it (row-major per source node); re-laid into Lf_ at the end
+    NdSegment *segs_d = nd_upload(tmp, P.segs, err);
+    if (!(nodes_ && Lm_ && segs_d)) return fail();
     // ---- setup-only arrays
     double *fronts = nd_alloc<double>(tmp, P.front_doubles, err);
     long long *a_dst = nd_upload(tmp, P.a_dst, err);
@@ -220,6 +204,7 @@ bool NdSolver::setup(const HostCsr &A, const NdParams &prm, hipStream_t st, std:
             nd_launch_gemm(gd, td, (int)ts.size() / 2, st);
         }
     }
+    nd_launch_repack((long long)P.segs.size(), segs_d, Lm_, Lf_, st);
     int sing_h = 0;
     const bool copied = hipMemcpyAsync(&sing_h, sing, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess;
     const hipError_t e = hipStreamSynchronize(st);
@@ -242,7 +227,7 @@ bool NdSolver::setup(const HostCsr &A, const NdParams &prm, hipStream_t st, std:
     leaf_ = P.leaf;
     max_np_ = P.max_np;
     factor_bytes_ = P.factor_bytes();
-    launches_ = 1 + (P.nlevels - 1) + P.nlevels;
+    launches_ = 2 * P.nlevels - 1;
     factor_seconds = now_s() - t1;
     why = 0;
     return true;
@@ -251,10 +236,8 @@ bool NdSolver::setup(const HostCsr &A, const NdParams &prm, hipStream_t st, std:
 void NdSolver::solve(const double *b, double *x, hipStream_t st) const
 {
     if (n_ <= 0) return;
-    nd_launch_permute(n_, perm_, b, w_, st);
-    for (int l = 1; l < nlevels_; ++l) nd_launch_forward(lev_[l].rows, lev_[l].nrows, lev_[l].wide_fwd, seg_ptr_, segs_, Lm_, w_, st);
-    for (int l = nlevels_ - 1; l >= 0; --l)
-        nd_launch_backward(lev_[l].rows, lev_[l].rnode, lev_[l].nrows, lev_[l].wide_bwd, n_, nodes_, idx_, Bm_, w_, perm_, x, st);
+    for (int l = 1; l < nlevels_; ++l) nd_launch_pass(true, fwd_[l].rows, fwd_[l].nrows, fwd_[l].nwide, n_, Lf_, fidx_, w_, b, x, st);
+    for (int l = nlevels_ - 1; l >= 0; --l) nd_launch_pass(false, bwd_[l].rows, bwd_[l].nrows, bwd_[l].nwide, n_, Bm_, bidx_, w_, b, x, st);
 }
 
 }  // namespace sparsh

@@ -56,17 +56,13 @@ private:
     int n_ = 0, nlevels_ = 0, nnodes_ = 0, leaf_ = 0, max_np_ = 0, launches_ = 0;
     size_t factor_bytes_ = 0;
     std::vector<void *> allocs_;
-    double *Bm_ = nullptr, *Lm_ = nullptr, *w_ = nullptr;
-    int *perm_ = nullptr, *idx_ = nullptr, *seg_ptr_ = nullptr;
-    NdSegment *segs_ = nullptr;
-    NdDevNode *nodes_ = nullptr;
-    struct Level {
-        int *rows = nullptr;   // new row indices of the level's pivot rows
-        int *rnode = nullptr;  // node of each of them
-        int nrows = 0;
-        bool wide_fwd = false, wide_bwd = false;  // one workgroup per row instead of one wave per row
+    double *Bm_ = nullptr, *Lf_ = nullptr, *w_ = nullptr;  // backward rows, forward rows (per target row), [c | x] in the new numbering
+    int *bidx_ = nullptr, *fidx_ = nullptr;
+    struct Pass {
+        NdRow *rows = nullptr;
+        int nrows = 0, nwide = 0;
     };
-    std::vector<Level> lev_;
+    std::vector<Pass> fwd_, bwd_;  // per tree level
 };
 
 // launchers of nd_kernels.hip
@@ -75,10 +71,9 @@ void nd_launch_extend_add(const NdDevNode *nodes, const int *children, int nchil
 void nd_launch_invert(const NdDevNode *nodes, const int *list, int count, double *fronts, double *Bm, int *singular, hipStream_t st);
 void nd_launch_copy_block(const double *src, int lds, double *dst, int ldd, int rows, int cols, hipStream_t st);
 void nd_launch_gemm(const NdGemm *problems, const int *tiles, int ntiles, hipStream_t st);
-void nd_launch_permute(int n, const int *perm, const double *b, double *c, hipStream_t st);
-void nd_launch_forward(const int *rows, int nrows, bool wide, const int *seg_ptr, const NdSegment *segs, const double *Lm, double *c, hipStream_t st);
-void nd_launch_backward(const int *rows, const int *rnode, int nrows, bool wide, int n, const NdDevNode *nodes, const int *idx, const double *Bm,
-                        double *w, const int *perm, double *x, hipStream_t st);
+void nd_launch_repack(long long nseg, const NdSegment *segs, const double *Lh, double *Lf, hipStream_t st);
+void nd_launch_pass(bool forward, const NdRow *rows, int nrows, int nwide, int n, const double *M, const int *idx, double *w, const double *b, double *x,
+                    hipStream_t st);
 constexpr int kNdSmallPivot = 1024;  // largest pivot block the one-workgroup inversion takes
 
 }  // namespace sparsh

@@ -203,35 +203,32 @@ int main(int argc, char **argv)
             gemm(F + (size_t)p * ld, ld, Bk + p, ld, F + (size_t)p * ld + p, ld, u, u, p, 1.0, 1);
         }
     }
-    // ---- solve: permute, forward pull per level, backward per level
-    std::vector<double> b((size_t)n), x((size_t)n, 0.0), w((size_t)2 * n, 0.0);
+    // ---- solve, as the device does it: Lh re-laid per target row, then both passes as gathered dots over vec = [c | x | b]
+    std::vector<double> Lf(P.l_doubles, 0.0);
+    for (const NdSegment &g : P.segs)
+        for (int t = 0; t < g.p; ++t) Lf[(size_t)g.dst + t] = Lm[(size_t)g.moff + t];
+    std::vector<double> b((size_t)n), x((size_t)n, 0.0), w((size_t)2 * n, std::nan(""));
     for (int i = 0; i < n; ++i) b[i] = 1.0 + 0.37 * ((i * 31) % 17);
-    for (int i = 0; i < n; ++i) w[i] = b[P.perm[i]];
+    auto vec = [&](int g) { return g < 2 * n ? w[g] : b[g - 2 * n]; };
+    auto gdot = [&](const NdRow &R, const std::vector<double> &M, const std::vector<int> &idx) {
+        double acc = 0.0;
+        for (int t = 0; t < R.len; ++t) acc += M[(size_t)R.moff + t] * vec(idx[(size_t)R.ioff + t]);
+        return acc;
+    };
+    size_t rows_seen = 0;
     for (int l = 1; l < P.nlevels; ++l)
-        for (int k : P.level_nodes[l])
-            for (int r = P.nodes[k].first; r < P.nodes[k].first + P.nodes[k].np; ++r) {
-                double acc = 0.0;
-                for (int s = P.seg_ptr[r]; s < P.seg_ptr[r + 1]; ++s) {
-                    const NdSegment &g = P.segs[s];
-                    if (P.nodes[P.node_of_row[g.first]].level >= l) return std::printf("segment source not below its target\n"), 5;
-                    for (int t = 0; t < g.p; ++t) acc += Lm[(size_t)g.moff + t] * w[g.first + t];
-                }
-                w[r] -= acc;
-            }
-    for (int l = P.nlevels - 1; l >= 0; --l)
-        for (int k : P.level_nodes[l]) {
-            const NdNode &nd = P.nodes[k];
-            const int len = nd.np + nd.nu;
-            for (int r = 0; r < nd.np; ++r) {
-                double acc = 0.0;
-                for (int t = 0; t < len; ++t) {
-                    const int g = t < nd.np ? nd.first + t : n + P.upd_idx[nd.upd + t - nd.np];  // the gather list nd_solver.cpp builds
-                    acc += Bm[nd.boff + (size_t)r * len + t] * w[g];
-                }
-                w[n + nd.first + r] = acc;
-                x[P.perm[nd.first + r]] = acc;
-            }
+        for (const NdRow &R : P.fwd[l].rows) {
+            if (R.bsrc != P.perm[R.out] || P.nodes[P.node_of_row[R.out]].level != l) return std::printf("bad forward row record\n"), 5;
+            w[R.out] = b[R.bsrc] - gdot(R, Lf, P.fidx);
         }
+    for (int l = P.nlevels - 1; l >= 0; --l)
+        for (const NdRow &R : P.bwd[l].rows) {
+            const double a = gdot(R, Bm, P.bidx);
+            w[n + R.out] = a;
+            x[R.bsrc] = a;
+            ++rows_seen;
+        }
+    if (rows_seen != (size_t)n) return std::printf("backward rows do not cover the system\n"), 5;
     double rn = 0.0, bn = 0.0;
     for (int i = 0; i < n; ++i) {
         double s = b[i];

@@ -112,7 +112,7 @@ def test_nested_dissection_solver_vs_sparse_lu(name, gen, leaf, merge):
     try:
         info = A.coarse_info()
         assert A.nlevels == 1 and info["rows"] == n and not info["dense"] and info["form"] == "nested_dissection"
-        assert info["nd_levels"] >= 2 and info["nd_launches_per_solve"] == 2 * info["nd_levels"]
+        assert info["nd_levels"] >= 2 and info["nd_launches_per_solve"] == 2 * info["nd_levels"] - 1
         assert info["nd_leaf"] == (leaf or 64)
         if "above_1024" in name:
             assert info["nd_max_pivot"] > 1024
@@ -125,7 +125,8 @@ def test_nested_dissection_solver_vs_sparse_lu(name, gen, leaf, merge):
             x = A.op_coarse(b)
             xr = lu.solve(b)
             assert np.linalg.norm(x - xr) <= 1e-11 * np.linalg.norm(xr), name
-            assert np.linalg.norm(b - S @ x) <= 1e-11 * np.linalg.norm(b)
+            # residual: as small as the sparse LU's own (the FEM operator's solution is 1e4 times its right-hand side: eps ||A|| ||x|| counts)
+            assert np.linalg.norm(b - S @ x) <= max(1e-11 * np.linalg.norm(b), 10.0 * np.linalg.norm(b - S @ xr))
         # deterministic: no atomics anywhere in the factorisation or the solve
         assert np.array_equal(A.op_coarse(np.ones(n)), A.op_coarse(np.ones(n)))
     finally:

@@ -262,6 +262,68 @@ def test_config2_full_size_properties():
     assert abs(z1 @ b2 - z2 @ b1) <= 1e-10 * abs(z1 @ b2)
 
 
+@pytest.mark.parametrize("form", ["nd", "bt"])
+def test_config1_full_size_properties(form):
+    """configs[1] at its stated size (5-pt 2D Poisson 1000^2 = 1 000 000 rows) with the DEFAULT, i.e. the reference's, level
+    policy (/root/reference/src/AMG_phases.cpp:51,77,89): 6 levels and a 31 250-row coarsest level for the device direct solver --
+    the nested-dissection factorisation (default) and the block-tridiagonal one in its interface form (window 128) --
+    through properties that need no oracle run at this size."""
+    import scipy.sparse as sp
+
+    rp, ci, v = problems.poisson2d(1000)
+    n = len(rp) - 1
+    assert n == 1000000 and rp[-1] == 4996000
+    S = sp.csr_matrix((v, ci, rp), shape=(n, n))
+    A = sa.sp_matrix_mg(rp, ci, v).set_coarse_form(form).setup(sa.default_params(**QUIET))
+    try:
+        levels = [A.level_info(l)["nrow"] for l in range(A.nlevels)]
+        assert levels == [1000000, 500000, 250000, 125000, 62500, 31250]
+        info = A.coarse_info()
+        assert info["rows"] == 31250 and not info["dense"] and not info["extended"]
+        if form == "bt":
+            assert info["form"] == "block_tridiagonal" and info["window"] == 128
+        else:
+            assert info["form"] == "nested_dissection" and info["nd_launches_per_solve"] <= 16 and info["bytes"] < 64e6
+        b = np.ones(n)
+        x = np.zeros(n)
+        h, rc = A.solve("pcg", b, x)
+        assert rc == 0 and h[-1] <= 1e-8 and len(h) < 60 and np.all(np.diff(np.log(h)) < 0.7)
+        true_r = np.linalg.norm(b - S @ x)
+        assert abs(true_r - h[-1]) <= 100 * np.finfo(float).eps * 8.0 * np.linalg.norm(x)
+        assert true_r <= 5e-8
+        # stand-alone AMG V(7,7) cycles (AMG_Solver_CPU_baseline) converge too
+        xa = np.zeros(n)
+        ha, rca = A.solve("amg", b, xa)
+        assert rca == 0 and ha[-1] <= 1e-8 and np.linalg.norm(b - S @ xa) <= 5e-8
+        # the coarsest-level solve itself: residual of A_L x = b_L through the level's own SpMV
+        L = A.nlevels - 1
+        rng = np.random.default_rng(0)
+        bl = rng.standard_normal(levels[-1])
+        xl = A.op_coarse(bl)
+        assert np.linalg.norm(bl - A.op_spmv(L, xl)) <= 1e-10 * np.linalg.norm(bl)
+        # SpMV bitwise against a scalar-order host product on a sample of rows
+        xx = rng.standard_normal(n)
+        y = A.op_spmv(0, xx)
+        for i in rng.integers(0, n, size=2000):
+            sacc = 0.0
+            for j in range(rp[i], rp[i + 1]):
+                sacc += v[j] * xx[ci[j]]
+            assert y[i] == sacc
+        # the V(7,7) cycle from a zero guess is linear and symmetric (SPD preconditioner)
+        b1 = rng.standard_normal(n)
+        b2 = rng.standard_normal(n)
+        z1 = np.zeros(n)
+        A.vcycle(b1, z1, iterations=1)
+        z2 = np.zeros(n)
+        A.vcycle(b2, z2, iterations=1)
+        z12 = np.zeros(n)
+        A.vcycle(2.0 * b1 - 0.5 * b2, z12, iterations=1)
+        assert np.linalg.norm(z12 - (2.0 * z1 - 0.5 * z2)) <= 1e-12 * np.linalg.norm(z12)
+        assert abs(z1 @ b2 - z2 @ b1) <= 1e-10 * abs(z1 @ b2)
+    finally:
+        A.close()
+
+
 @pytest.mark.parametrize("n", [1, 2, 5, 63, 64, 65, 257])
 def test_tiny_matrices(n):
     """Sizes around the 64-lane wave / slice boundary and degenerate ones; single-level solves."""
