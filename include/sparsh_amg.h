@@ -54,7 +54,7 @@ typedef struct sparsh_params {
     int coarse_limit;   /* largest coarsest level max_levels may leave for the device direct solver
                            (default 40000: up to ~1.3 M rows the hierarchy is exactly the reference's,
                            src/AMG_phases.cpp:51,77,89).  If max_levels would leave more, coarsening
-                           continues by the same rule until <= limit_upper rows (documented deviation
+                           continues by the same rule until <= extend_until rows (documented deviation
                            from the reference, which hands any size to PARDISO; 1<<30 disables it).
                                                                                [SPARSH_COARSE_LIMIT] */
     int host_threads;   /* OpenMP threads for the host setup (0 = all)        [SPARSH_THREADS] */
@@ -77,6 +77,12 @@ typedef struct sparsh_params {
                            (one GEMV per V-cycle); larger ones with the block-tridiagonal factorisation of
                            the RCM-ordered operator, factored and applied on the device (csrc/coarse.cpp).
                            Default 8192.                                       [SPARSH_DENSE_LIMIT] */
+    int extend_until;   /* where a hierarchy that had to be extended past max_levels (see coarse_limit) stops:
+                           0 (default) = at the first level of at most coarse_limit rows, i.e. as soon as the
+                           device direct solver can take over -- the closest to the reference's "6 levels, then
+                           a direct solve" that fits; > 0 = at the first level of at most that many rows
+                           (4000 = limit_upper: round 2's behaviour, 13 levels at 10 M rows).
+                                                                               [SPARSH_EXTEND_UNTIL] */
 } sparsh_params;
 
 typedef struct sparsh_handle_s *sparsh_handle;
@@ -223,7 +229,7 @@ int sparsh_coarse_info(sparsh_handle h, int *info6, long *bytes);
  *     one launch per tree level upwards and one downwards (csrc/nd_plan.cpp, nd_solver.cpp, nd_kernels.hip).
  *   form 1: block-tridiagonal factorisation of the RCM-ordered operator (csrc/coarse.cpp), ~ n / bandwidth dependent steps.
  * leaf > 0: largest subgraph kept as one dense block (default 64); merge_rows >= 0: separators of successive bisections are
- * eliminated as one pivot block while their total stays below this (default 192; 0 = plain bisection).
+ * eliminated as one pivot block while their total stays below this (default 384; 0 = plain bisection).
  * sparsh_coarse_nd_info: info6 = {nested dissection in use (1/0), tree nodes, tree levels, largest pivot block,
  * launches per solve, leaf size}. */
 int sparsh_set_coarse_form(sparsh_handle h, int form, int leaf, int merge_rows);

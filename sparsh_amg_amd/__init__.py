@@ -58,6 +58,7 @@ class Params(C.Structure):
         ("replicate_rows", C.c_int),
         ("precond_fp32", C.c_int),
         ("dense_limit", C.c_int),
+        ("extend_until", C.c_int),
     ]
 
 

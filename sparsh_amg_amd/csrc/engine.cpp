@@ -475,6 +475,7 @@ int Engine::setup_host(const sparsh_params &p)
     sp.coarsening = p.coarsening;
     sp.coarse_limit = p.coarse_limit;
     if (p.dense_limit > 0) sp.dense_limit = p.dense_limit;
+    sp.extend_until = p.extend_until;
     sp.host_threads = p.host_threads;
     sp.print = p.print_setup != 0;
     if (!build_hierarchy(A0_, sp, H_)) {
@@ -492,6 +493,7 @@ int Engine::setup_host(const sparsh_params &p)
             if (sp.print) std::printf("note: %s -- extending the hierarchy instead\n", perr.c_str());
             SetupParams sp2 = sp;
             sp2.coarse_limit = sp.dense_limit;
+            sp2.extend_until = sp.limit_upper;
             const double before = H_.seconds;
             if (!build_hierarchy(A0_, sp2, H_)) {
                 error = H_.error;

@@ -558,11 +558,13 @@ bool build_hierarchy(const HostCsr &A0, const SetupParams &prm, HostHierarchy &H
         const bool within_ref = l < prm.max_levels - 1;
         // reference rule: coarsen while n > limit_upper and fewer than max_levels levels exist
         // (src/AMG_phases.cpp:51,77); whatever is left goes to the direct solver (:89).  That is
-        // followed up to coarse_limit rows (dense inverse up to dense_limit, block-tridiagonal
-        // factorisation above).  Opt-out for very large problems: if max_levels would leave more than
-        // coarse_limit rows, keep coarsening by the same rule until n <= limit_upper.
+        // followed up to coarse_limit rows (dense inverse up to dense_limit, device factorisation
+        // above).  Opt-out for very large problems: if max_levels would leave more than coarse_limit
+        // rows, keep coarsening by the same rule until the direct solver can take over (n <= coarse_limit;
+        // extend_until > 0: until n <= extend_until, e.g. limit_upper as in round 2).
         if (!within_ref && n > prm.coarse_limit) H.extended = true;
-        if (!(n > prm.limit_upper && (within_ref || H.extended))) break;
+        const int stop_at = within_ref ? prm.limit_upper : std::max(prm.limit_upper, prm.extend_until > 0 ? prm.extend_until : prm.coarse_limit);
+        if (!(n > stop_at && (within_ref || H.extended))) break;
         if (prm.print) std::printf("Level %d:\t%d\n", l, n);
         HostLevel &L = H.levels[l];
         if (prm.coarsening == 1) {

@@ -54,6 +54,7 @@ struct SetupParams {
     int coarsening = 0;  // 0 HEM, 1 Beck
     int coarse_limit = 40000;  // largest coarsest level max_levels may leave (above: keep coarsening)
     int dense_limit = 8192;    // largest coarsest level solved with an explicit dense inverse
+    int extend_until = 0;      // an extended hierarchy stops at the first level of at most this many rows (0: coarse_limit)
     int host_threads = 0;
     bool print = true;
 };

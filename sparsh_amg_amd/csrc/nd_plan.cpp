@@ -399,6 +399,11 @@ bool nd_make_plan(const HostCsr &A, const NdParams &prm, NdPlan &P, std::string 
             return false;
         }
     }
+    if ((double)P.factor_bytes() > prm.max_dense_fraction * 8.0 * (double)n * (double)n) {
+        err = "nested dissection: the operator's graph has no usable separators (factors of " + std::to_string(P.factor_bytes() >> 20) + " MB against " +
+              std::to_string(((size_t)n * n * 8) >> 20) + " MB for the dense inverse of its " + std::to_string(n) + " rows)";
+        return false;
+    }
     if (P.factor_bytes() > prm.max_factor_bytes || P.front_bytes() > prm.max_front_bytes) {
         err = "nested dissection: factors of " + std::to_string(P.factor_bytes() >> 20) + " MB (fronts " + std::to_string(P.front_bytes() >> 20) +
               " MB) exceed the budget; lower coarse_limit so the hierarchy is extended instead";

@@ -8,7 +8,14 @@ in the image).  Two right-hand sides:
     M + dt K, the shadow residual r0 stays parallel to it and r.r0 / (Ap.r0) ends as 0/0; the reference
     has no breakdown checks: `while (res > tol1)`, src/AMG_main_solvers.cpp:397) -- the residual becomes NaN;
   * b = 1e-3 * N(0,1) (numpy default_rng(4)): converges.
-Takes ~6 minutes of 8-thread CPU time.  Data only: iteration counts, residual heads/tails, solution checks."""
+Takes ~6 minutes of 8-thread CPU time.  Data only: iteration counts, residual heads/tails, solution checks.
+
+  --extra  (round 3; adds to the existing file, ~10 more minutes): for the random right-hand side
+  * true_residuals_k1_6: ||b - A x_k||_2 computed with scipy from the oracle's iterate after exactly k = 1..6 iterations of
+    AMG-PBiCGStab and AMG-PCG (runs capped at k iterations) -- what the device's iterates are held to, independent of either
+    side's residual recurrence;
+  * thread_sensitivity: AMG-PBiCGStab iteration counts of the oracle itself with 1, 2 and 8 OpenMP threads (its dot products are
+    chunked per thread, so the summation order changes) -- the spread the loose iteration-count band of the GPU test has to cover."""
 import json
 import os
 import sys
@@ -43,5 +50,40 @@ def main():
         json.dump(out, f, indent=1)
 
 
+def extra():
+    import scipy.sparse as sp
+
+    path = os.path.join(ROOT, "tests", "golden", "config4_fem_oracle.json")
+    with open(path) as f:
+        out = json.load(f)
+    rp, ci, v = problems.fem_unstructured(525825)
+    n = len(rp) - 1
+    O = oracle.Csr(rp, ci, v)
+    S = sp.csr_matrix((v, ci, rp), shape=(n, n))
+    b = np.random.default_rng(4).standard_normal(n) * 1e-3
+    for method in ("pbicg", "pcg"):
+        tr, cnt, rec = [], [], []
+        for k in range(1, 7):
+            x, h = oracle.solve(method, O, b, prm=oracle.params(threads=8, max_iter=k))
+            tr.append(float(np.linalg.norm(b - S @ x)))
+            cnt.append(len(h))
+            rec.append(float(h[-1]))
+            print(method, k, len(h), tr[-1], h[-1], flush=True)
+        out["random_rhs"][method]["true_residuals_k1_6"] = tr
+        out["random_rhs"][method]["history_length_at_cap_k1_6"] = cnt
+        out["random_rhs"][method]["recurrence_residual_at_cap_k1_6"] = rec
+    sens = {}
+    for th in (1, 2, 8):
+        x, h = oracle.solve("pbicg", O, b, prm=oracle.params(threads=th, max_iter=2000))
+        sens[str(th)] = {"iterations": len(h), "final_residual": float(h[-1]), "true_residual": float(np.linalg.norm(b - S @ x))}
+        print("threads", th, sens[str(th)], flush=True)
+    out["random_rhs"]["pbicg"]["thread_sensitivity"] = sens
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+
+
 if __name__ == "__main__":
-    main()
+    if "--extra" in sys.argv:
+        extra()
+    else:
+        main()

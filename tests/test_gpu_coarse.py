@@ -95,7 +95,7 @@ def _fem(npts):
 
 
 @pytest.mark.parametrize("name,gen,leaf,merge", [
-    ("p3d_24", lambda: problems.poisson3d(24), 0, -1),            # 13 824 rows, defaults (leaf 64, merged separators up to 192 rows)
+    ("p3d_24", lambda: problems.poisson3d(24), 0, -1),            # 13 824 rows, defaults (leaf 64, merged separators up to 384 rows)
     ("p3d_24_plain_bisection", lambda: problems.poisson3d(24), 16, 0),   # small leaves, no merging: a deep tree
     ("p3d_24_big_blocks", lambda: problems.poisson3d(24), 200, 600),      # few levels, wide pivot blocks
     ("p2d_150", lambda: problems.poisson2d(150), 0, -1),
@@ -193,7 +193,7 @@ def test_too_wide_operator_is_refused():
     """A random sparsity pattern has neither band structure nor separators: when the caller's parameters leave no room to extend
     the hierarchy (one level forced) the setup must say so instead of building something huge."""
     rp, ci, v = problems.random_spd(20000, 9, seed=5)
-    for form, msg in (("bt", "too wide"), ("nd", "no usable separator")):
+    for form, msg in (("bt", "too wide"), ("nd", "no usable separators")):
         A = sa.sp_matrix_mg(rp, ci, v).set_coarse_form(form)
         with pytest.raises(sa.SparshError) as e:
             A.setup(sa.default_params(**QUIET, **ONE_LEVEL))
