@@ -233,6 +233,10 @@ int sparsh_coarse_info(sparsh_handle h, int *info6, long *bytes);
  * sparsh_coarse_nd_info: info6 = {nested dissection in use (1/0), tree nodes, tree levels, largest pivot block,
  * launches per solve, leaf size}. */
 int sparsh_set_coarse_form(sparsh_handle h, int form, int leaf, int merge_rows);
+/* the same cap for the nodes near the root of the dissection tree: top_merge_rows for the root, halved per tree depth until it
+ * meets merge_rows (default 2048; 0 = merge_rows everywhere).  Near the root a tree level holds 1, 2, 4 ... nodes and costs two
+ * dependent launches per solve whatever it holds. */
+int sparsh_set_coarse_top_merge(sparsh_handle h, int top_merge_rows);
 int sparsh_coarse_nd_info(sparsh_handle h, int *info6);
 /* Interface form of the block-tridiagonal solve: where the RCM band is narrow against the block (2 * window <= block,
  * window = bandwidth rounded up to 64) only the first / last `window` rows of a block couple to its neighbours, so the

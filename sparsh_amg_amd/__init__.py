@@ -112,6 +112,7 @@ def _load():
         "sparsh_set_coarse_block": (C.c_int, [H, C.c_int]),
         "sparsh_set_coarse_form": (C.c_int, [H, C.c_int, C.c_int, C.c_int]),
         "sparsh_coarse_nd_info": (C.c_int, [H, c_int_p]),
+        "sparsh_set_coarse_top_merge": (C.c_int, [H, C.c_int]),
         "sparsh_setup_seconds": (C.c_double, [H]),
         "sparsh_vcycle": (C.c_int, [H, c_dbl_p, c_dbl_p, C.c_int, c_dbl_p, C.c_int, c_int_p]),
         "sparsh_vcycle_dev": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int, c_dbl_p, C.c_int, c_int_p]),
@@ -430,10 +431,12 @@ class sp_matrix_mg:
                 "extended": bool(info[5]), "bytes": nbytes.value, "window": win.value,
                 "nd_nodes": nd[1], "nd_levels": nd[2], "nd_max_pivot": nd[3], "nd_launches_per_solve": nd[4], "nd_leaf": nd[5]}
 
-    def set_coarse_form(self, form="nd", leaf=0, merge_rows=-1):
+    def set_coarse_form(self, form="nd", leaf=0, merge_rows=-1, top_merge_rows=-1):
         """Direct solver of a coarsest level above dense_limit rows: "nd" (nested-dissection multifrontal, default) or "bt"
-        (block tridiagonal, round 2's); leaf / merge_rows tune the dissection (0 / -1 = defaults).  Call before setup."""
+        (block tridiagonal, round 2's); leaf / merge_rows / top_merge_rows tune the dissection (0 / -1 = defaults).  Call before setup."""
         _check(lib.sparsh_set_coarse_form(self._h, {"nd": 0, "bt": 1}[form], int(leaf), int(merge_rows)))
+        if top_merge_rows >= 0:
+            _check(lib.sparsh_set_coarse_top_merge(self._h, int(top_merge_rows)))
         return self
 
     def set_coarse_block(self, rows=0):

@@ -504,6 +504,14 @@ int sparsh_set_coarse_form(sparsh_handle h, int form, int leaf, int merge_rows)
     return SPARSH_OK;
 }
 
+int sparsh_set_coarse_top_merge(sparsh_handle h, int top_merge_rows)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    if (top_merge_rows < 0) return fail(SPARSH_EINVAL, "top_merge_rows must be >= 0");
+    h->eng->coarse_mut().set_nd_params(0, -1, top_merge_rows);
+    return SPARSH_OK;
+}
+
 int sparsh_coarse_nd_info(sparsh_handle h, int *info6)
 {
     REQUIRE_HOST(h);

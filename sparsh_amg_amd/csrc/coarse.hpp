@@ -81,10 +81,11 @@ public:
     // 0 = nested dissection above dense_limit (default), 1 = block-tridiagonal (round 2's solver, kept for A/B runs)
     void set_form(int form) { form_ = form; }
     int form() const { return form_; }
-    void set_nd_params(int leaf, int merge_rows)
+    void set_nd_params(int leaf, int merge_rows, int top_merge_rows = -1)
     {
         if (leaf > 0) nd_prm_.leaf = leaf;
         if (merge_rows >= 0) nd_prm_.merge_rows = merge_rows;
+        if (top_merge_rows >= 0) nd_prm_.top_merge_rows = top_merge_rows;
     }
     const NdParams &nd_params() const { return nd_prm_; }
     int n() const { return n_; }

@@ -266,7 +266,10 @@ struct Dissector {
                 }
             }
             if (!any) break;
-            if ((int)(sep.size() + add.size()) > prm.merge_rows) {
+            // near the root the tree is narrow (1, 2, 4 ... nodes per level) and a level costs two dependent launches whatever it holds:
+            // there the cap is top_merge_rows halved per depth, further down merge_rows
+            const int cap = std::max(prm.merge_rows, depth < 30 ? prm.top_merge_rows >> depth : 0);
+            if ((int)(sep.size() + add.size()) > cap) {
                 // undo the round: every vertex back under its piece's set id
                 for (const Piece &pc : pieces)
                     for (int v : pc.verts) owner[v] = pc.sid;
@@ -399,7 +402,7 @@ bool nd_make_plan(const HostCsr &A, const NdParams &prm, NdPlan &P, std::string 
             return false;
         }
     }
-    if ((double)P.factor_bytes() > prm.max_dense_fraction * 8.0 * (double)n * (double)n) {
+    if (P.factor_bytes() > ((size_t)256 << 20) && (double)P.factor_bytes() > prm.max_dense_fraction * 8.0 * (double)n * (double)n) {
         err = "nested dissection: the operator's graph has no usable separators (factors of " + std::to_string(P.factor_bytes() >> 20) + " MB against " +
               std::to_string(((size_t)n * n * 8) >> 20) + " MB for the dense inverse of its " + std::to_string(n) + " rows)";
         return false;

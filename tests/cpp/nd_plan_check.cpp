@@ -3,7 +3,7 @@
 // emulation of what the device kernels of csrc/nd_kernels.hip do (scatter, extend-add by child slot, Gauss-Jordan
 // inverse of the pivot block with partial pivoting, the three products, forward pull, backward product) and the
 // result is checked against A x = b.  No GPU needed.
-//   argv: kind(grid2|grid3|box|rand|blocks) size leaf [merge_rows]      (box: size = nx * 1000000 + ny * 1000 + nz)
+//   argv: kind(grid2|grid3|box|rand|blocks) size leaf [merge_rows [top_merge_rows]]      (box: size = nx * 1000000 + ny * 1000 + nz)
 //   env ND_PLAN_ONLY=1: statistics of the plan only (large cases)
 #include <algorithm>
 #include <cmath>
@@ -131,6 +131,7 @@ int main(int argc, char **argv)
     NdParams prm;
     prm.leaf = leaf;
     if (merge >= 0) prm.merge_rows = merge;
+    if (argc > 5) prm.top_merge_rows = std::atoi(argv[5]);
     NdPlan P;
     std::string err;
     if (!nd_make_plan(A, prm, P, err)) {

@@ -82,8 +82,34 @@ def extra():
         json.dump(out, f, indent=1)
 
 
+def extra2():
+    """rounding_sensitivity: the oracle's own AMG-PBiCGStab iteration count when the right-hand side is perturbed at the level of
+    one rounding error (b_i * (1 + 2^-52 * s_i), s_i in {-1, 0, 1} from default_rng(seed)): the oracle's reductions are chunked
+    independently of the thread count (1, 2 and 8 threads give the same 424 iterations bit for bit), so this -- not a thread sweep --
+    is what shows how far rounding alone moves the count on this operator."""
+    path = os.path.join(ROOT, "tests", "golden", "config4_fem_oracle.json")
+    with open(path) as f:
+        out = json.load(f)
+    rp, ci, v = problems.fem_unstructured(525825)
+    n = len(rp) - 1
+    O = oracle.Csr(rp, ci, v)
+    b = np.random.default_rng(4).standard_normal(n) * 1e-3
+    runs = []
+    for seed in (11, 12, 13):
+        s = np.random.default_rng(seed).integers(-1, 2, size=n).astype(np.float64)
+        bp = b * (1.0 + 2.0 ** -52 * s)
+        x, h = oracle.solve("pbicg", O, bp, prm=oracle.params(threads=8, max_iter=2000))
+        runs.append({"seed": seed, "iterations": len(h), "final_residual": float(h[-1])})
+        print(runs[-1], flush=True)
+    out["random_rhs"]["pbicg"]["rounding_sensitivity"] = runs
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+
+
 if __name__ == "__main__":
-    if "--extra" in sys.argv:
+    if "--extra2" in sys.argv:
+        extra2()
+    elif "--extra" in sys.argv:
         extra()
     else:
         main()

@@ -27,7 +27,7 @@ def run(name, rp, ci, v, methods, rhs="ones", **params):
         A.set_coarse_block(int(os.environ["SPARSH_COARSE_BLOCK"]))
     if os.environ.get("SPARSH_COARSE_FORM"):   # "nd[,leaf[,merge_rows]]" or "bt": A/B of the two device factorisations
         f = os.environ["SPARSH_COARSE_FORM"].split(",")
-        A.set_coarse_form(f[0], int(f[1]) if len(f) > 1 else 0, int(f[2]) if len(f) > 2 else -1)
+        A.set_coarse_form(f[0], int(f[1]) if len(f) > 1 else 0, int(f[2]) if len(f) > 2 else -1, int(f[3]) if len(f) > 3 else -1)
     A.setup(sa.default_params(print_setup=0, print_solve=0, **params))
     out["levels"] = [A.level_info(l)["nrow"] for l in range(A.nlevels)]
     out["level_kernels"] = [A.level_kernel(l) for l in range(A.nlevels - 1)]
@@ -78,10 +78,20 @@ def main():
         res["C3D_poisson3d_100"] = run("100^3", *problems.poisson3d(100), ["amg", "pcg"])
     if want("C3D_poisson3d_100_extended_hierarchy"):
         res["C3D_poisson3d_100_extended_hierarchy"] = run("100^3 ext", *problems.poisson3d(100), ["amg", "pcg"], coarse_limit=8192)
+    # the reference's own 6-level policy one size further than the default coarse_limit allows: 136^3 leaves a
+    # 78 608-row coarsest level; next to it the default (hierarchy extended until <= 40 000 rows)
+    if want("C3D_poisson3d_136_reference_policy"):
+        res["C3D_poisson3d_136_reference_policy"] = run("136^3 ref", *problems.poisson3d(136), ["amg", "pcg"], coarse_limit=100000)
+    if want("C3D_poisson3d_136_default"):
+        res["C3D_poisson3d_136_default"] = run("136^3", *problems.poisson3d(136), ["amg", "pcg"])
     if want("C3D_poisson3d_216"):
         res["C3D_poisson3d_216"] = run("C3D", *problems.poisson3d(216), ["amg", "pcg"])
-    if want("C3D_poisson3d_216_10_levels_block_tridiagonal"):
-        res["C3D_poisson3d_216_10_levels_block_tridiagonal"] = run("C3D 10 levels", *problems.poisson3d(216), ["amg", "pcg"], max_levels=10, coarse_limit=1 << 30)
+    if want("C3D_poisson3d_216_round2_hierarchy"):  # extended until <= limit_upper rows: 13 levels, dense 2468-row coarsest level
+        res["C3D_poisson3d_216_round2_hierarchy"] = run("C3D 13 levels", *problems.poisson3d(216), ["amg", "pcg"], extend_until=4000)
+    if want("C3D_poisson3d_216_8_levels"):          # stop one level earlier: 78 732-row coarsest level
+        res["C3D_poisson3d_216_8_levels"] = run("C3D 8 levels", *problems.poisson3d(216), ["amg", "pcg"], coarse_limit=80000)
+    if want("C3D_poisson3d_216_reference_policy"):  # the reference's own 6 levels: 314 928 rows to the direct solver (what PARDISO gets in the reference)
+        res["C3D_poisson3d_216_reference_policy"] = run("C3D 6 levels", *problems.poisson3d(216), ["pcg"], coarse_limit=1 << 30)
     # nu = 6 sweeps: what the reference's GPU path effectively runs (smooth_iter without the +1 of the CPU path)
     if want("C3D_poisson3d_216_nu6"):
         res["C3D_poisson3d_216_nu6"] = run("C3D nu=6", *problems.poisson3d(216), ["amg", "pcg"], sweeps=6)

@@ -22,7 +22,7 @@ def run(case):
     A = sa.sp_matrix_mg(rp, ci, v)
     if os.environ.get("SPARSH_COARSE_FORM"):
         f = os.environ["SPARSH_COARSE_FORM"].split(",")
-        A.set_coarse_form(f[0], int(f[1]) if len(f) > 1 else 0, int(f[2]) if len(f) > 2 else -1)
+        A.set_coarse_form(f[0], int(f[1]) if len(f) > 1 else 0, int(f[2]) if len(f) > 2 else -1, int(f[3]) if len(f) > 3 else -1)
     A.setup(sa.default_params(print_setup=0, print_solve=0))
     info = A.coarse_info()
     t = A.bench_op("coarse", A.nlevels - 1, 57)  # 3 warm-up + 57
@@ -44,12 +44,15 @@ def summarize(d):
     print("# launch  pass      grid   duration_us  gap_before_us")
     t0 = int(last[0]["Start_Timestamp"])
     tot = 0.0
+    gkey = next((k for k in ("Grid_Size", "Grid_Size_X", "Grid_X") if last and k in last[0]), None)
+    wkey = next((k for k in ("Workgroup_Size", "Workgroup_Size_X", "Workgroup_X") if last and k in last[0]), None)
     for i, r in enumerate(last):
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        grid = int(r[gkey]) // max(1, int(r[wkey]) if wkey else 256) if gkey else -1
         gap = (s - prev_end) / 1e3 if prev_end is not None else float("nan")
         prev_end = e
         tot += (e - s) / 1e3
-        print(f"{i:6d}  {'forward ' if 'true' in r['Kernel_Name'] else 'backward'}  {int(r['Grid_Size']) // 256:6d}  {(e - s) / 1e3:10.2f}  {gap:10.2f}")
+        print(f"{i:6d}  {'forward ' if 'true' in r['Kernel_Name'] else 'backward'}  {grid:6d}  {(e - s) / 1e3:10.2f}  {gap:10.2f}")
     print(f"# first start -> last end: {(prev_end - t0) / 1e3:.2f} us; sum of kernel durations {tot:.2f} us")
 
 

@@ -25,7 +25,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 N_GRID = 216
 
 
-def run(grid=N_GRID, cfg=None, no_fold=False, layout_out=None, fem=0, idx16=None, iters=0, coarse_limit=8192):
+def run(grid=N_GRID, cfg=None, no_fold=False, layout_out=None, fem=0, idx16=None, iters=0, coarse_limit=None):
     import numpy as np
 
     import sparsh_amg_amd as sa
@@ -37,10 +37,11 @@ def run(grid=N_GRID, cfg=None, no_fold=False, layout_out=None, fem=0, idx16=None
         A.set_const_slots(False)
     if idx16 is not None:
         A.set_index_compression(idx16)
-    # coarse_limit = 8192: keep the coarsest level on the dense-inverse path here; the block-tridiagonal
-    # factorisation issues tens of thousands of small launches, which the counter-collection mode of the
-    # profiler does not survive (segfault inside rocprofv3); the finest-level kernels measured are unaffected
-    A.setup(sa.default_params(print_setup=0, print_solve=0, coarse_limit=coarse_limit))
+    # Default parameters, as the timed run.  (Round 2 forced coarse_limit = 8192 here: the block-tridiagonal factorisation
+    # issues ~32 k launches and rocprofv3's counter-collection mode segfaults beyond a few ten thousand dispatches of ANY kernel
+    # -- tools/micro/many_launches.hip: 10 000 trivial launches pass, 40 000 crash inside the tool,
+    # profiles/r03_pmc/rocprofv3_pmc_dispatch_limit.txt.  The nested-dissection factorisation issues a few hundred.)
+    A.setup(sa.default_params(print_setup=0, print_solve=0, **({} if coarse_limit is None else {"coarse_limit": coarse_limit})))
     cfg = cfg or os.environ.get("SPARSH_PMC_CFG")  # "kind,vec,nt,remap": override the per-operator policy (diagnostics)
     if cfg:
         A.set_kernel_config(*[int(t) for t in cfg.split(",")])
@@ -220,7 +221,7 @@ if __name__ == "__main__":
     ap.add_argument("--fem", type=int, default=0, help="--run on the unstructured P1-FEM stand-in with this many points instead of the grid")
     ap.add_argument("--idx16", type=int, default=None, help="--run: sparsh_set_index_compression mode (2 = every operator)")
     ap.add_argument("--iters", type=int, default=0, help="--run: also K whole AMG-PCG iterations between marker launches (bytes per iteration)")
-    ap.add_argument("--coarse-limit", type=int, default=8192, help="--run: sparsh_params.coarse_limit (default keeps the coarsest level dense)")
+    ap.add_argument("--coarse-limit", type=int, default=None, help="--run: sparsh_params.coarse_limit (default: the library's)")
     a = ap.parse_args()
     if a.run:
         run(a.grid, a.kcfg, a.no_fold, a.layout, a.fem, a.idx16, a.iters, a.coarse_limit)
