@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include "coarse.hpp"
 
@@ -81,6 +83,7 @@ bool NdSolver::setup(const HostCsr &A, const NdParams &prm, hipStream_t st, std:
         release();
         return false;
     };
+    const double t_up = now_s();
     // ---- persistent arrays: the rows of both passes, their gather lists, the work vector
     Bm_ = nd_alloc<double>(allocs_, P.b_doubles, err);
     Lf_ = nd_alloc<double>(allocs_, P.l_doubles, err);
@@ -140,6 +143,23 @@ bool NdSolver::setup(const HostCsr &A, const NdParams &prm, hipStream_t st, std:
         if (!(S2 && c0 && c1 && piv && cmap)) return fail();
     }
     const double t1 = now_s();
+    // SPARSH_ND_TIMING=1: synchronise after every phase and print where the factorisation time goes
+    const bool timing = std::getenv("SPARSH_ND_TIMING") != nullptr;
+    double t_ext = 0.0, t_inv = 0.0, t_big = 0.0, t_gemm = 0.0;
+    auto lap = [&](double &acc) {
+        if (!timing) return;
+        static thread_local double last = 0.0;
+        (void)hipStreamSynchronize(st);
+        const double t = now_s();
+        if (&acc != &t_ext || last != 0.0) acc += t - last;
+        last = t;
+    };
+    if (timing) {
+        (void)hipStreamSynchronize(st);
+        std::printf("nd timing: plan %.3f s, uploads + scatter %.3f s\n", plan_seconds, now_s() - t_up);
+        double dummy = 0.0;
+        lap(dummy);
+    }
     for (int l = 0; l < P.nlevels; ++l) {
         const std::vector<int> &ln = P.level_nodes[l];
         // extend-add: children of this level's nodes, one pass per child slot
@@ -158,6 +178,7 @@ bool NdSolver::setup(const HostCsr &A, const NdParams &prm, hipStream_t st, std:
             if (!chd) return fail();
             nd_launch_extend_add(nodes_, chd, (int)ch.size(), max_nu, rel, fronts, st);
         }
+        lap(t_ext);
         // pivot-block inverses
         std::vector<int> small;
         for (int k : ln)
@@ -167,12 +188,14 @@ bool NdSolver::setup(const HostCsr &A, const NdParams &prm, hipStream_t st, std:
             if (!sl) return fail();
             nd_launch_invert(nodes_, sl, (int)small.size(), fronts, Bm_, sing, st);
         }
+        lap(t_inv);
         for (int k : ln) {
             const NdNode &nd = P.nodes[k];
             if (nd.np <= kNdSmallPivot) continue;
             const int ld = nd.np + nd.nu;
             bt_launch_invert(nd.np, ld, fronts + nd.foff, S2, c0, c1, piv, cmap, sing, Bm_ + nd.boff, st);
         }
+        lap(t_big);
         // -D^-1 F12 -> B_k[:, np:], F21 D^-1 -> Lh_k ; then F22 += F21 (-D^-1 F12)
         std::vector<NdGemm> g1, g2;
         std::vector<int> t1v, t2v;
@@ -203,7 +226,9 @@ bool NdSolver::setup(const HostCsr &A, const NdParams &prm, hipStream_t st, std:
             if (!gd || !td) return fail();
             nd_launch_gemm(gd, td, (int)ts.size() / 2, st);
         }
+        lap(t_gemm);
     }
+    if (timing) std::printf("nd timing: extend-add %.3f s, one-workgroup inversions %.3f s, whole-chip inversions %.3f s, products %.3f s\n", t_ext, t_inv, t_big, t_gemm);
     nd_launch_repack((long long)P.segs.size(), segs_d, Lm_, Lf_, st);
     int sing_h = 0;
     const bool copied = hipMemcpyAsync(&sing_h, sing, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess;

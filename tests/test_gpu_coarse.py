@@ -94,21 +94,22 @@ def _fem(npts):
     return problems.fem_unstructured(npts)
 
 
-@pytest.mark.parametrize("name,gen,leaf,merge", [
-    ("p3d_24", lambda: problems.poisson3d(24), 0, -1),            # 13 824 rows, defaults (leaf 64, merged separators up to 384 rows)
-    ("p3d_24_plain_bisection", lambda: problems.poisson3d(24), 16, 0),   # small leaves, no merging: a deep tree
-    ("p3d_24_big_blocks", lambda: problems.poisson3d(24), 200, 600),      # few levels, wide pivot blocks
-    ("p2d_150", lambda: problems.poisson2d(150), 0, -1),
-    ("nonsym2d_170", lambda: _nonsym2d(170), 0, -1),               # 28 900 rows, nonsymmetric
-    ("nonsym3d_22", lambda: _nonsym3d(22), 0, -1),                 # not diagonally dominant: pivoting inside the pivot blocks
-    ("p3d_ragged", lambda: problems.poisson3d(21), 32, 100),
-    ("fem_20000", lambda: _fem(20000), 0, -1),                     # unstructured P1-FEM mesh: irregular separators, many children per node
-    ("p3d_40_top_separator_above_1024_rows", lambda: problems.poisson3d(40), 0, -1),  # 64 000 rows: the top pivot block takes the whole-chip inversion
+@pytest.mark.parametrize("name,gen,leaf,merge,top", [
+    ("p3d_24", lambda: problems.poisson3d(24), 0, -1, -1),            # 13 824 rows, defaults (leaf 64, merged separators up to 384 rows, 2048 at the root)
+    ("p3d_24_plain_bisection", lambda: problems.poisson3d(24), 16, 0, 0),   # small leaves, no merging: a deep tree
+    ("p3d_24_big_blocks", lambda: problems.poisson3d(24), 200, 600, 600),      # few levels, wide pivot blocks
+    ("p2d_150", lambda: problems.poisson2d(150), 0, -1, -1),
+    ("p2d_150_no_top_merge", lambda: problems.poisson2d(150), 0, -1, 0),
+    ("nonsym2d_170", lambda: _nonsym2d(170), 0, -1, -1),               # 28 900 rows, nonsymmetric
+    ("nonsym3d_22", lambda: _nonsym3d(22), 0, -1, -1),                 # not diagonally dominant: pivoting inside the pivot blocks
+    ("p3d_ragged", lambda: problems.poisson3d(21), 32, 100, 300),
+    ("fem_20000", lambda: _fem(20000), 0, -1, -1),                     # unstructured P1-FEM mesh: irregular separators, many children per node
+    ("p3d_40_top_separator_above_1024_rows", lambda: problems.poisson3d(40), 0, -1, -1),  # 64 000 rows: the top pivot block takes the whole-chip inversion
 ])
-def test_nested_dissection_solver_vs_sparse_lu(name, gen, leaf, merge):
+def test_nested_dissection_solver_vs_sparse_lu(name, gen, leaf, merge, top):
     rp, ci, v = gen()
     n = len(rp) - 1
-    A = sa.sp_matrix_mg(rp, ci, v).set_coarse_form("nd", leaf, merge).setup(sa.default_params(**QUIET, **ONE_LEVEL, dense_limit=2000))
+    A = sa.sp_matrix_mg(rp, ci, v).set_coarse_form("nd", leaf, merge, top).setup(sa.default_params(**QUIET, **ONE_LEVEL, dense_limit=2000))
     try:
         info = A.coarse_info()
         assert A.nlevels == 1 and info["rows"] == n and not info["dense"] and info["form"] == "nested_dissection"

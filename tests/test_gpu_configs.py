@@ -600,14 +600,19 @@ def test_config4_iteration_count_band_is_backed_by_the_oracles_own_sensitivity(c
     """VERDICT r2 item 6 iii: the loose band on the AMG-PBiCGStab iteration count is justified by data, not by the device's number.
     The fixture records (a) that the oracle's count does not depend on its thread count (chunked reductions: 1, 2, 8 threads give the
     same history), and (b) how far the oracle's OWN count moves when its right-hand side is perturbed by one rounding error per
-    entry.  The device's count has to lie within that spread widened by a quarter on either side."""
+    entry: 424 unperturbed; 298, 485 and one breakdown (NaN at 361) perturbed.  The device's count has to lie within the spread of
+    the converged oracle runs widened by a quarter on either side."""
     A, S, g = config4_full
     go = g["random_rhs"]["pbicg"]
     ts = go["thread_sensitivity"]
     assert len({ts[k]["iterations"] for k in ts}) == 1
-    counts = [go["iterations"]] + [r["iterations"] for r in go["rounding_sensitivity"]]
+    runs = go["rounding_sensitivity"]
+    # one of the three perturbed oracle runs does not even converge: it ends in 0/0 after 361 iterations (final residual NaN) --
+    # BiCGStab without breakdown checks (src/AMG_main_solvers.cpp:397) on this operator is that fragile in the oracle itself
+    assert any(r["final_residual"] is None or not np.isfinite(r["final_residual"]) for r in runs)
+    counts = [go["iterations"]] + [r["iterations"] for r in runs if r["final_residual"] is not None and np.isfinite(r["final_residual"])]
     lo, hi = min(counts), max(counts)
-    assert hi > lo  # the oracle itself is that sensitive
+    assert hi >= 1.3 * lo  # converged oracle runs alone: 298 ... 485 iterations
     b = np.random.default_rng(4).standard_normal(A.nrow) * 1e-3
     x = np.zeros(A.nrow)
     h, rc = A.solve("pbicg", b, x)
