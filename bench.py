@@ -664,6 +664,7 @@ def main():
                 "general_values_layout": general,
                 "kernel_families": families,
                 "comm_us": comm_us,
+                "comm_schedule": ({"measured": A.comm_measured(), "levels": A.comm_schedule()} if mode == "partitioned" or world > 1 else None),
                 "setup_seconds_host": round(A.setup_seconds, 2),
                 "generate_seconds": round(t_gen, 2),
             },

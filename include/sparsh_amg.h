@@ -65,7 +65,8 @@ typedef struct sparsh_params {
                            (1 = reference behaviour: every iteration)                          */
     int use_graph;      /* capture one V-cycle into a hipGraph and replay it   [SPARSH_GRAPH]   */
     int replicate_rows; /* multi-GPU: levels with at most this many rows are held and computed by every
-                           rank (no halo exchange below that size)            [SPARSH_REPLICATE_ROWS] */
+                           rank (no halo exchange below that size).  0 (default): chosen at setup from the measured
+                           transport, see sparsh_set_comm_tuning (1 500 000 when that is off) [SPARSH_REPLICATE_ROWS] */
     int precond_fp32;   /* 0 (default): everything fp64, bitwise parity with the reference's arithmetic.
                            1: SPARSH_PCG / SPARSH_PBICG run their V-cycle on a float copy of the hierarchy (float values
                            and vectors: the sliced-diagonal value blocks where a level has that layout, the
@@ -370,6 +371,21 @@ int sparsh_comm_init_group(sparsh_handle h, void *group, int rank);
 /* fault injection for tests: from its ncalls-th halo exchange on (counted per rank, 0-based) the in-process
  * transport fails on every rank.  Solvers must then return SPARSH_ECOMM, and the handle keeps
  * returning it (sticky) until sparsh_setup is called again.  ncalls < 0 switches the hook off. */
+/* Multi-rank schedule chosen from measurements (round 3).  With more than one rank and replicate_rows <= 0 (the default)
+ * sparsh_setup first measures the transport it was given -- one neighbour exchange (latency and rate), the 16-byte all-reduce,
+ * one all-gather -- and the device's sweep floor and streaming rate, takes the slowest rank's numbers, models every level's
+ * share of a V(nu,nu) cycle as partitioned with deep halos / partitioned with one exchange per sweep / replicated, and
+ * partitions the prefix of levels (with one smoothing schedule) that minimises the total.  replicate_rows > 0 or
+ * sparsh_set_comm_tuning(h, 0) keep the caller's threshold and sparsh_set_deep_halo.
+ * sparsh_comm_schedule: info4 = {rows, boundary rows of a middle rank, partitioned, deep halo}, cost_us3 = modelled microseconds
+ * per V-cycle {deep halo, exchange per sweep, replicated}.  sparsh_comm_measured: m7 = {exchange us, exchange us/MB, all-reduce us,
+ * all-gather us, all-gather us/MB, sweep floor us, sweep us/MB}.
+ * sparsh_comm_group_set_delay (in-process test transport only): every transport call occupies the caller's stream that many
+ * microseconds first -- a slow link, to see the schedule move. */
+int sparsh_set_comm_tuning(sparsh_handle h, int mode);
+int sparsh_comm_schedule(sparsh_handle h, int level, int *info4, double *cost_us3);
+int sparsh_comm_measured(sparsh_handle h, double *m7);
+int sparsh_comm_group_set_delay(void *group, double microseconds);
 int sparsh_comm_group_fail_after(void *group, int ncalls);
 
 /* Host-only planning query (after sparsh_setup_host): the block of operator `which` (0 A_l, 1 P_l,

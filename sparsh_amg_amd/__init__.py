@@ -133,6 +133,10 @@ def _load():
         "sparsh_deep_prefix_spmv": (C.c_int, [H, C.c_int, C.c_int, c_dbl_p, c_dbl_p]),
         "sparsh_exchanges_issued": (C.c_long, [H]),
         "sparsh_comm_group_fail_after": (C.c_int, [C.c_void_p, C.c_int]),
+        "sparsh_comm_group_set_delay": (C.c_int, [C.c_void_p, C.c_double]),
+        "sparsh_set_comm_tuning": (C.c_int, [H, C.c_int]),
+        "sparsh_comm_schedule": (C.c_int, [H, C.c_int, c_int_p, c_dbl_p]),
+        "sparsh_comm_measured": (C.c_int, [H, c_dbl_p]),
         "sparsh_comm_init_group": (C.c_int, [H, C.c_void_p, C.c_int]),
         "sparsh_dist_local_op": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p]),
         "sparsh_dist_local_op_get": (C.c_int, [H, c_int_p, c_int_p, c_dbl_p, c_int_p, c_int_p, c_int_p, c_int_p]),
@@ -211,6 +215,11 @@ def comm_group_create(nranks: int):
 
 def comm_group_destroy(g):
     lib.sparsh_comm_group_destroy(g)
+
+
+def comm_group_set_delay(g, microseconds: float):
+    """In-process test transport: every transport call first occupies the caller's stream this long (a slow link)."""
+    _check(lib.sparsh_comm_group_set_delay(g, float(microseconds)))
 
 
 def comm_group_fail_after(g, ncalls: int):
@@ -448,6 +457,32 @@ class sp_matrix_mg:
         """Interface (window) form of the block-tridiagonal coarse solve, default on; call before setup."""
         _check(lib.sparsh_set_coarse_interface(self._h, int(enable)))
         return self
+
+    def set_comm_tuning(self, enable=True):
+        """Multi-rank setups: choose the partitioned levels and the smoothing schedule from the measured transport (default on when
+        replicate_rows <= 0); call before setup."""
+        _check(lib.sparsh_set_comm_tuning(self._h, int(bool(enable))))
+        return self
+
+    def comm_schedule(self):
+        """Per-level decision table of the measured multi-rank schedule, or None when none was made."""
+        out = []
+        for l in range(self.nlevels):
+            info = (C.c_int * 4)()
+            cost = (C.c_double * 3)()
+            rc = lib.sparsh_comm_schedule(self._h, l, info, cost)
+            if rc != 0:
+                return None
+            out.append({"level": l, "rows": info[0], "boundary_rows": info[1], "partitioned": bool(info[2]), "deep_halo": bool(info[3]),
+                        "model_us_deep_halo": round(cost[0], 2), "model_us_exchange_per_sweep": round(cost[1], 2), "model_us_replicated": round(cost[2], 2)})
+        return out
+
+    def comm_measured(self):
+        m = (C.c_double * 7)()
+        if lib.sparsh_comm_measured(self._h, m) != 0:
+            return None
+        keys = ("exchange_us", "exchange_us_per_MB", "allreduce_us", "allgather_us", "allgather_us_per_MB", "sweep_floor_us", "sweep_us_per_MB")
+        return {k: round(m[i], 3) for i, k in enumerate(keys)}
 
     def set_deep_halo(self, enable=True):
         """Deep-halo smoothing on partitioned levels (default on; call before setup)."""

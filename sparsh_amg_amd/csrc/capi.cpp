@@ -124,7 +124,7 @@ void sparsh_default_params(sparsh_params *p)
     p->print_solve = pr;
     p->check_every = 1;
     p->use_graph = env_int("SPARSH_GRAPH", 0);
-    p->replicate_rows = env_int("SPARSH_REPLICATE_ROWS", 1500000);
+    p->replicate_rows = env_int("SPARSH_REPLICATE_ROWS", 0);
     p->precond_fp32 = env_int("SPARSH_PRECOND_FP32", 0);
 }
 
@@ -625,6 +625,59 @@ int sparsh_comm_group_create(int nranks, void **group)
 }
 
 void sparsh_comm_group_destroy(void *group) { thread_group_destroy(static_cast<ThreadGroup *>(group)); }
+
+int sparsh_comm_group_set_delay(void *group, double microseconds)
+{
+    if (!group || microseconds < 0.0) return fail(SPARSH_EINVAL, "bad group / delay");
+    thread_group_set_delay(static_cast<ThreadGroup *>(group), microseconds);
+    return SPARSH_OK;
+}
+
+int sparsh_set_comm_tuning(sparsh_handle h, int mode)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    if (mode != 0 && mode != 1) return fail(SPARSH_EINVAL, "mode must be 0 (replicate_rows / set_deep_halo decide) or 1 (measured)");
+    h->eng->set_comm_tuning(mode);
+    return SPARSH_OK;
+}
+
+int sparsh_comm_schedule(sparsh_handle h, int level, int *info4, double *cost_us3)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    const auto &sc = h->eng->comm_schedule();
+    if (sc.empty()) return fail(SPARSH_ESTATE, "no measured schedule: one rank, tuning off, or replicate_rows given by the caller");
+    const auto &c = sc[level];
+    if (info4) {
+        info4[0] = c.rows;
+        info4[1] = c.halo_rows;
+        info4[2] = c.partitioned ? 1 : 0;
+        info4[3] = c.deep ? 1 : 0;
+    }
+    if (cost_us3) {
+        cost_us3[0] = c.cost_deep_us;
+        cost_us3[1] = c.cost_per_sweep_us;
+        cost_us3[2] = c.cost_replicated_us;
+    }
+    return SPARSH_OK;
+}
+
+int sparsh_comm_measured(sparsh_handle h, double *m7)
+{
+    REQUIRE_READY(h);
+    const auto &m = h->eng->comm_measured();
+    if (!m.valid) return fail(SPARSH_ESTATE, "the transport was not measured in this setup");
+    if (m7) {
+        m7[0] = m.exchange_us;
+        m7[1] = m.exchange_us_per_mb;
+        m7[2] = m.allreduce_us;
+        m7[3] = m.allgather_us;
+        m7[4] = m.allgather_us_per_mb;
+        m7[5] = m.sweep_floor_us;
+        m7[6] = m.sweep_us_per_mb;
+    }
+    return SPARSH_OK;
+}
 
 int sparsh_comm_group_fail_after(void *group, int ncalls)
 {

@@ -148,6 +148,7 @@ struct ThreadGroup {
     std::vector<double *> ptrs;
     std::vector<std::vector<double>> host;
     int fail_after = -1;  // test hook: every rank's exchange() number fail_after (0-based) and later ones fail
+    double delay_us = 0.0;  // test hook: every transport call first occupies the caller's stream this long (a slow link)
     void wait()
     {
         std::unique_lock<std::mutex> lk(m);
@@ -181,6 +182,11 @@ void thread_group_fail_after(ThreadGroup *g, int n)
     if (g) g->fail_after = n;
 }
 
+void thread_group_set_delay(ThreadGroup *g, double microseconds)
+{
+    if (g) g->delay_us = microseconds;
+}
+
 void thread_group_destroy(ThreadGroup *g)
 {
     if (!g) return;
@@ -212,6 +218,7 @@ public:
             (void)hipEventCreateWithFlags(&g->pub[rank], hipEventDisableTiming);
             (void)hipEventCreateWithFlags(&g->done[rank], hipEventDisableTiming);
         }
+        launch_spin(g->delay_us, st);
         // peers may still be pulling the previous exchange's data out of my sendbuf
         g->wait();
         if (primed)
@@ -257,6 +264,7 @@ public:
             (void)hipEventCreateWithFlags(&g->pub[rank], hipEventDisableTiming);
             (void)hipEventCreateWithFlags(&g->done[rank], hipEventDisableTiming);
         }
+        launch_spin(g->delay_us, st);
         g->wait();  // peers may still be pulling the previous exchange's data out of my sendbuf
         if (primed)
             for (int r = 0; r < size; ++r)
@@ -289,6 +297,7 @@ public:
     }
     bool allreduce_sum(double *dev, int n, hipStream_t st) override
     {
+        launch_spin(g->delay_us, st);
         std::vector<double> &mine = g->host[rank];
         mine.resize((size_t)n);
         (void)hipMemcpyAsync(mine.data(), dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st);
@@ -304,6 +313,7 @@ public:
     }
     bool allgather(double *full, const Partition &part, hipStream_t st) override
     {
+        launch_spin(g->delay_us, st);
         (void)hipStreamSynchronize(st);
         g->ptrs[rank] = full;
         g->wait();

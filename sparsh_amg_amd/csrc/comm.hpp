@@ -69,6 +69,7 @@ struct ThreadGroup;
 ThreadGroup *thread_group_create(int nranks);
 void thread_group_destroy(ThreadGroup *g);
 void thread_group_fail_after(ThreadGroup *g, int n);  // test hook: exchanges from call n on fail on every rank
+void thread_group_set_delay(ThreadGroup *g, double microseconds);  // test hook: every transport call costs this much more (a slow link)
 std::unique_ptr<Comm> make_thread_comm(ThreadGroup *g, int rank);
 
 }  // namespace sparsh

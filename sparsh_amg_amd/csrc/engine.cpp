@@ -13,6 +13,7 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -775,6 +776,219 @@ bool Engine::debug_prefix_spmv(int l, int rows, const double *x_ext, double *y)
     return check(hipStreamSynchronize(st_), "sync");
 }
 
+// ---- transport-measured schedule (multi-rank setups) -------------------------------------------------------------------
+// Nobody can tune replicate_rows / deep-halo by hand for a node this code has never run on, so the setup measures: one
+// neighbour exchange (small and large: latency + rate), the 16-byte all-reduce, one all-gather (small and large), and the
+// device's streaming rate and launch floor (an axpby, small and large).  Every rank measures, the slowest rank's numbers
+// count.  A level's share of one V(nu,nu) cycle is then modelled three ways -- partitioned with deep halos (4 exchanges,
+// redundant ghost-row sweeps), partitioned with one exchange per sweep (2 nu + 2 exchanges), replicated (no exchange, G times
+// the rows) -- and the cheapest consistent choice wins: a prefix of levels is partitioned, with one smoothing schedule.
+namespace {
+
+double stream_bytes_per_row(const HostCsr &A)
+{
+    // what the layout builder will stream per row and sweep (mirrors its own rule on a sample of rows): constant-coefficient
+    // stencils fold into a table (24 B of vectors + 1 B of masks), few diagonals stream 8 B per entry, the rest CSR's 12 B
+    const int n = A.nrow;
+    if (n <= 0) return 36.0;
+    std::vector<std::pair<int, double>> seen;
+    const int step = std::max(1, n / 2048);
+    bool many = false;
+    for (int i = 0; i < n && !many; i += step)
+        for (int j = A.rowptr[i]; j < A.rowptr[i + 1] && !many; ++j) {
+            const std::pair<int, double> e(A.col[j] - i, A.val[j]);
+            if (std::find(seen.begin(), seen.end(), e) == seen.end()) {
+                seen.push_back(e);
+                many = seen.size() > 64;
+            }
+        }
+    const double per_row = (double)A.nnz() / n;
+    if (seen.size() <= 8) return 25.0;
+    if (!many) return 8.0 * per_row + 27.0;
+    return 12.0 * per_row + 36.0;
+}
+
+int boundary_rows(const HostCsr &A, int lo, int hi)
+{
+    // entries of the input vector a rank owning rows [lo, hi) needs from the others
+    std::vector<char> mark((size_t)A.ncol, 0);
+    int cnt = 0;
+    for (int i = lo; i < hi; ++i)
+        for (int j = A.rowptr[i]; j < A.rowptr[i + 1]; ++j) {
+            const int c = A.col[j];
+            if ((c < lo || c >= hi) && !mark[c]) {
+                mark[c] = 1;
+                ++cnt;
+            }
+        }
+    return cnt;
+}
+
+}  // namespace
+
+bool Engine::measure_transport()
+{
+    meas_ = CommMeasured();
+    const int G = comm_->size, me = comm_->rank;
+    const int small = 128, large = 1 << 16;  // doubles per neighbour
+    const int agn_small = 1 << 14, agn_large = 1 << 21;
+    const int axn_small = 1 << 14, axn_large = 1 << 22;
+    double *vec = nullptr, *ag = nullptr, *ax = nullptr, *slots = nullptr;
+    auto cleanup = [&]() {
+        for (double *q : {vec, ag, ax, slots})
+            if (q) (void)hipFree(q);
+    };
+    if (hipMalloc(reinterpret_cast<void **>(&vec), (size_t)4 * large * 8) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&ag), (size_t)agn_large * 8) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&ax), (size_t)2 * axn_large * 8) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&slots), (size_t)G * 8 * 8) != hipSuccess) {
+        cleanup();
+        return false;
+    }
+    (void)hipMemsetAsync(vec, 0, (size_t)4 * large * 8, st_);
+    (void)hipMemsetAsync(ag, 0, (size_t)agn_large * 8, st_);
+    (void)hipMemsetAsync(ax, 0, (size_t)2 * axn_large * 8, st_);
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    bool good = true;
+    auto timed = [&](int reps, const std::function<bool()> &fn) {
+        for (int i = 0; i < 2 && good; ++i) good = fn();
+        HIPCHK(hipEventRecord(e0, st_));
+        for (int i = 0; i < reps && good; ++i) good = fn();
+        HIPCHK(hipEventRecord(e1, st_));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        return (double)ms * 1e3 / reps;  // microseconds per call
+    };
+    auto ring_plan = [&](int cnt) {
+        DevPlan pl;
+        pl.nloc = 2 * cnt;
+        int k = 0;
+        for (int peer : {me - 1, me + 1}) {
+            if (peer < 0 || peer >= G) continue;
+            HaloSeg r, sd;
+            r.peer = sd.peer = peer;
+            r.off = k * cnt;
+            r.cnt = sd.cnt = cnt;
+            sd.off = 0;
+            sd.start = k * cnt;  // a contiguous run of the own entries: sent in place
+            pl.recv.push_back(r);
+            pl.send.push_back(sd);
+            ++k;
+        }
+        pl.nhalo = k * cnt;
+        return pl;
+    };
+    double m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        const DevPlan ps = ring_plan(small), pl = ring_plan(large);
+        m[0] = timed(20, [&] { return comm_->exchange(ps, vec, st_); });
+        m[1] = timed(10, [&] { return comm_->exchange(pl, vec, st_); });
+    }
+    m[2] = timed(20, [&] { return comm_->allreduce_sum(slots, 2, st_); });
+    {
+        const Partition ps = make_partition(agn_small, G), pl = make_partition(agn_large, G);
+        m[3] = timed(10, [&] { return comm_->allgather(ag, ps, st_); });
+        m[4] = timed(5, [&] { return comm_->allgather(ag, pl, st_); });
+    }
+    m[5] = timed(50, [&] {
+        launch_axpby(axn_small, 0.5, ax, 0.5, ax + axn_large, st_);
+        return true;
+    });
+    m[6] = timed(20, [&] {
+        launch_axpby(axn_large, 0.5, ax, 0.5, ax + axn_large, st_);
+        return true;
+    });
+    // the slowest rank's numbers count, and every rank must decide from the same ones: each rank writes its slot, all-reduce, max
+    std::vector<double> all((size_t)G * 8, 0.0);
+    for (int q = 0; q < 8; ++q) all[(size_t)me * 8 + q] = m[q];
+    good = good && check(hipMemcpyAsync(slots, all.data(), all.size() * 8, hipMemcpyHostToDevice, st_), "hipMemcpy") && comm_->allreduce_sum(slots, G * 8, st_) &&
+           check(hipMemcpyAsync(all.data(), slots, all.size() * 8, hipMemcpyDeviceToHost, st_), "hipMemcpy") && check(hipStreamSynchronize(st_), "hipStreamSynchronize");
+    HIPCHK(hipEventDestroy(e0));
+    HIPCHK(hipEventDestroy(e1));
+    cleanup();
+    if (!good) return false;
+    for (int q = 0; q < 8; ++q) {
+        m[q] = 0.0;
+        for (int r = 0; r < G; ++r) m[q] = std::max(m[q], all[(size_t)r * 8 + q]);
+    }
+    const double mb = 1.0 / 1048576.0;
+    meas_.exchange_us = m[0];
+    meas_.exchange_us_per_mb = std::max(0.0, (m[1] - m[0]) / ((large - small) * 8.0 * mb));
+    meas_.allreduce_us = m[2];
+    meas_.allgather_us = m[3];
+    meas_.allgather_us_per_mb = std::max(0.0, (m[4] - m[3]) / ((agn_large - agn_small) * 8.0 * mb));
+    meas_.sweep_floor_us = m[5];
+    meas_.sweep_us_per_mb = std::max(1e-6, (m[6] - m[5]) / ((axn_large - axn_small) * 24.0 * mb));
+    meas_.valid = true;
+    return true;
+}
+
+void Engine::tune_comm_schedule(const sparsh_params &p)
+{
+    const int G = comm_->size;
+    const int nl = (int)H_.levels.size();
+    if (G <= 1 || nl < 2 || !measure_transport()) return;
+    const double mb = 1.0 / 1048576.0;
+    const int nu = std::max(1, p.sweeps);
+    auto sweep_us = [&](double rows, double bpr) { return meas_.sweep_floor_us + rows * bpr * mb * meas_.sweep_us_per_mb; };
+    auto exch_us = [&](double bytes) { return meas_.exchange_us + bytes * mb * meas_.exchange_us_per_mb; };
+    sched_.assign((size_t)nl, CommLevelChoice());
+    std::vector<double> part_deep((size_t)nl, 0.0), part_sweep((size_t)nl, 0.0), repl((size_t)nl, 0.0);
+    for (int l = 0; l < nl; ++l) {
+        const HostCsr &A = H_.levels[l].A;
+        const int n = A.nrow;
+        CommLevelChoice &c = sched_[l];
+        c.rows = n;
+        if (l == nl - 1) continue;  // the coarsest level is solved directly, replicated
+        const double bpr = stream_bytes_per_row(A);
+        const Partition part = make_partition(n, G);
+        const int g = G / 2;
+        const int lo = part.lo(g), hi = part.hi(g);
+        const int h = boundary_rows(A, lo, hi);
+        c.halo_rows = h;
+        const double own = (double)(hi - lo);
+        // deep halos: nu sweeps of a leg also update the ghost layers <= nu + 1 - s: h nu (nu + 1) / 2 extra row-sweeps per leg
+        const double ghost = own > 0 ? (double)h * (nu + 1) / 2.0 : 0.0;
+        c.cost_deep_us = 2.0 * nu * sweep_us(own + ghost, bpr) + sweep_us(own, bpr) + 4.0 * exch_us((double)h * (nu + 1) * 8.0);
+        c.cost_per_sweep_us = (2.0 * nu + 1.0) * sweep_us(own, bpr) + (2.0 * nu + 2.0) * exch_us((double)h * 8.0);
+        c.cost_replicated_us = (2.0 * nu + 1.0) * sweep_us((double)n, bpr);
+        part_deep[l] = c.cost_deep_us;
+        part_sweep[l] = c.cost_per_sweep_us;
+        repl[l] = c.cost_replicated_us;
+    }
+    const bool deep_allowed = deep_halo_ && p.sweeps >= 1 && !p.precond_fp32;
+    double best = -1.0;
+    int best_lr = 0;
+    bool best_deep = deep_allowed;
+    for (int lr = 0; lr < nl; ++lr) {       // levels [0, lr) partitioned
+        if (lr > 0 && H_.levels[lr - 1].A.nrow <= 64 * G) break;
+        for (int deep = 0; deep < 2; ++deep) {
+            if (deep && !deep_allowed) continue;
+            if (lr == 0 && deep) continue;
+            double t = 0.0;
+            for (int l = 0; l < nl - 1; ++l) t += l < lr ? (deep ? part_deep[l] : part_sweep[l]) : repl[l];
+            if (lr > 0) t += meas_.allgather_us + (double)H_.levels[lr].A.nrow * 8.0 * mb * meas_.allgather_us_per_mb;
+            if (best < 0.0 || t < best) {
+                best = t;
+                best_lr = lr;
+                best_deep = deep != 0;
+            }
+        }
+    }
+    tuned_repl_level_ = best_lr;
+    tuned_deep_ = best_deep;
+    for (int l = 0; l < nl; ++l) {
+        sched_[l].partitioned = l < best_lr;
+        sched_[l].deep = l < best_lr && best_deep;
+    }
+    if (p.print_setup && comm_->rank == 0) {
+        std::printf("transport measured: exchange %.1f us + %.2f us/MB, all-reduce %.1f us, all-gather %.1f us + %.2f us/MB; device sweep floor %.1f us, %.2f us/MB\n",
+                    meas_.exchange_us, meas_.exchange_us_per_mb, meas_.allreduce_us, meas_.allgather_us, meas_.allgather_us_per_mb, meas_.sweep_floor_us, meas_.sweep_us_per_mb);
+        std::printf("schedule: %d of %d levels partitioned over %d ranks, %s\n", best_lr, nl, G, best_lr == 0 ? "everything replicated" : (best_deep ? "deep-halo smoothing" : "one exchange per sweep"));
+    }
+}
+
 int Engine::setup(const sparsh_params &p)
 {
     prm_ = p;
@@ -806,15 +1020,25 @@ int Engine::setup(const sparsh_params &p)
     prm_ = p;
 
     // ---- row partition of every level (multi-GPU).  Levels at or below replicate_rows, and always
-    // the coarsest one (dense direct solve), are held and computed by every rank.
+    // the coarsest one (dense direct solve), are held and computed by every rank -- or, with more than one rank and the
+    // tuner on, the levels the measured transport says are cheaper replicated.
     const int nl = (int)H_.levels.size();
     parts_.assign((size_t)nl, Partition());
     repl_level_ = 0;
+    tuned_repl_level_ = -1;
+    sched_.clear();
+    // replicate_rows <= 0 (default): the tuner decides; a positive value is the caller's own threshold, as in round 2
+    const int replicate_rows = p.replicate_rows > 0 ? p.replicate_rows : 1500000;
+    if (G > 1 && comm_tune_ != 0 && p.replicate_rows <= 0) tune_comm_schedule(p);
     {
         bool repl = (G == 1);
         for (int l = 0; l < nl; ++l) {
             const int n = H_.levels[l].A.nrow;
-            if (!repl && (n <= std::max(p.replicate_rows, 64 * G) || l == nl - 1)) repl = true;
+            if (tuned_repl_level_ >= 0) {
+                if (!repl && (l >= tuned_repl_level_ || n <= 64 * G || l == nl - 1)) repl = true;
+            } else if (!repl && (n <= std::max(replicate_rows, 64 * G) || l == nl - 1)) {
+                repl = true;
+            }
             if (repl) {
                 parts_[l] = Partition::whole(n, G);
             } else {
@@ -847,7 +1071,7 @@ int Engine::setup(const sparsh_params &p)
         } else {
             const Partition &pl = parts_[l];
             d.n = pl.hi(me) - pl.lo(me);
-            d.deep = deep_halo_ && prm_.sweeps >= 1 && !prm_.precond_fp32;
+            d.deep = deep_halo_ && prm_.sweeps >= 1 && !prm_.precond_fp32 && (tuned_repl_level_ < 0 || tuned_deep_);
             if (d.deep) {
                 // deep-halo layout: own rows + K = sweeps + 1 ghost layers; exchange plans of depth 1 (SpMV-type
                 // calls outside a smoothing leg), K-1 (right-hand side of a leg) and K (iterate of a leg)

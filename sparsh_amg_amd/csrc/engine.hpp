@@ -115,6 +115,22 @@ public:
     // deep halo (default on for partitioned runs): one exchange per smoothing leg instead of one per sweep; read at setup
     void set_deep_halo(bool on) { deep_halo_ = on; }
     bool deep_halo() const { return deep_halo_; }
+    // Multi-rank setup: measure the transport (neighbour exchange latency and rate, 16-byte all-reduce, all-gather) and the
+    // device's sweep rate, then choose from those numbers which levels are partitioned and whether the partitioned levels smooth
+    // with deep halos or exchange per sweep (mode 1, default).  Mode 0: replicate_rows / set_deep_halo decide, as in round 2.
+    void set_comm_tuning(int mode) { comm_tune_ = mode; }
+    struct CommLevelChoice {
+        int rows = 0, halo_rows = 0;
+        bool partitioned = false, deep = false;
+        double cost_deep_us = 0.0, cost_per_sweep_us = 0.0, cost_replicated_us = 0.0;  // modelled time of the level's part of one V-cycle
+    };
+    struct CommMeasured {
+        double exchange_us = 0.0, exchange_us_per_mb = 0.0, allreduce_us = 0.0, allgather_us = 0.0, allgather_us_per_mb = 0.0;
+        double sweep_floor_us = 0.0, sweep_us_per_mb = 0.0;
+        bool valid = false;
+    };
+    const std::vector<CommLevelChoice> &comm_schedule() const { return sched_; }
+    const CommMeasured &comm_measured() const { return meas_; }
     long exchanges_issued() const { return n_exchanges_; }
     // test hook: y[0, rows) = (A_l x_ext)[0, rows) on the local operator of a deep-halo level, no exchange
     bool debug_prefix_spmv(int l, int rows, const double *x_ext, double *y);
@@ -213,6 +229,13 @@ private:
     bool dist_ = false;
     bool overlap_ = false;          // multi-GPU: overlap halo exchange with interior slices
     bool deep_halo_ = true;         // multi-GPU: deep-halo smoothing on the partitioned levels
+    int comm_tune_ = 1;
+    int tuned_repl_level_ = -1;     // >= 0: number of partitioned levels chosen by tune_comm_schedule
+    bool tuned_deep_ = true;
+    std::vector<CommLevelChoice> sched_;
+    CommMeasured meas_;
+    bool measure_transport();
+    void tune_comm_schedule(const sparsh_params &p);
     long n_exchanges_ = 0;          // transport calls issued (halo / staged exchanges; diagnostics)
     hipStream_t st2_ = nullptr;     // exchange stream of the overlap path
     hipEvent_t ev_ready_ = nullptr, ev_halo_ = nullptr;

@@ -2042,6 +2042,21 @@ void launch_fill(int n, double v, double *x, hipStream_t st)
     hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, st, n, v, x);
 }
 
+namespace {
+// busy-waits `ticks` of the constant 100 MHz wall clock: an artificial transport latency on a stream (virtual-rank tests)
+__global__ void spin_kernel(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace
+
+void launch_spin(double microseconds, hipStream_t st)
+{
+    if (microseconds <= 0.0) return;
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st, (long long)(microseconds * 100.0));
+}
+
 void launch_copy_int(int n, const int *x, int *y, hipStream_t st)
 {
     if (n <= 0) return;

@@ -181,6 +181,7 @@ void launch_gemv(int n, const double *M, const double *b, double *x, hipStream_t
 void launch_fill(int n, double v, double *x, hipStream_t st);
 void launch_copy(int n, const double *x, double *y, hipStream_t st);
 void launch_copy_int(int n, const int *x, int *y, hipStream_t st);  // PMC calibration of 4-byte streams
+void launch_spin(double microseconds, hipStream_t st);              // occupies the stream for that long (injected transport latency, tests)
 // y = a*x + b*y with host scalars
 void launch_axpby(int n, double a, const double *x, double b, double *y, hipStream_t st);
 // partial sums of x.y (nblocks returned through *nblk)

@@ -4,8 +4,8 @@
 // Factorisation, one tree level at a time from the leaves up (all nodes of a level in the same launches):
 //   scatter      entries of the permuted operator -> fronts (once)
 //   extend-add   F_parent[rel, rel] += F22 of each child, one pass per child slot (so two children never race)
-//   invert       D^-1 of the pivot block, Gauss-Jordan with partial pivoting inside the block (one workgroup per node;
-//                pivot blocks above kNdSmallPivot rows go through the whole-chip inversion of coarse_kernels.hip)
+//   invert       D^-1 of the pivot block, Gauss-Jordan with partial pivoting inside the block: one workgroup per node up to
+//                kNdTinyPivot rows; larger blocks of a level together, spread over the chip, one launch per pivot step
 //   gemm         -D^-1 F12 -> B_k ; F21 D^-1 -> Lh_k ; F22 += F21 (-D^-1 F12)      (batched 64 x 64 tiles, fp64)
 // Solve (2 * levels - 1 launches): per level upwards c[r] = b[perm r] - (row of Lh laid out per target row) . c ; per level
 // downwards x[P_k] = B_k [c[P_k]; x[U_k]], scattered back to the caller's numbering; both through the same gathered-dot
@@ -49,33 +49,37 @@ __global__ __launch_bounds__(kNB) void nd_extend_add_kernel(const NdDevNode *__r
     for (int j = lane; j < c.nu; j += 64) dst[rel[j]] += src[j];
 }
 
-// In-place Gauss-Jordan inversion with partial pivoting of the pivot block (np x np at the top left of the front, leading
-// dimension np + nu) of one node per workgroup; the inverse goes to the first np columns of B_k (same leading dimension).
+// Gauss-Jordan inversion with partial pivoting of a SMALL pivot block (np <= kNdTinyPivot rows, at the top left of the front, leading
+// dimension np + nu), one workgroup per node, the whole block in LDS; the inverse goes to the first np columns of B_k.
 //   step k: p = argmax_{i >= k} |M[i][k]| (lowest index on ties); rows k, p swapped; row k scaled by 1 / pivot with
 //   M[k][k] = 1 / pivot; every other row i: M[i][j] -= f_i * M[k][j], M[i][k] = -f_i / pivot  (f_i = old M[i][k]).
 //   (PA)^-1 = A^-1 P^-1: the columns are swapped back in reverse pivot order at the end.
-constexpr int kInvThreads = 1024;
+constexpr int kInvThreads = 256;
 
 __global__ __launch_bounds__(kInvThreads) void nd_invert_kernel(const NdDevNode *__restrict__ nodes, const int *__restrict__ list,
-                                                               double *__restrict__ fronts, double *__restrict__ Bm, int *__restrict__ singular)
+                                                               const double *__restrict__ fronts, double *__restrict__ Bm, int *__restrict__ singular)
 {
-    __shared__ double prow[kNdSmallPivot], fcol[kNdSmallPivot];
-    __shared__ int cm[kNdSmallPivot], pivs[kNdSmallPivot];
+    __shared__ double M[kNdTinyPivot * (kNdTinyPivot + 1)];
+    __shared__ double prow[kNdTinyPivot], fcol[kNdTinyPivot];
+    __shared__ int cm[kNdTinyPivot], pivs[kNdTinyPivot];
     __shared__ double smax[kInvThreads / 64];
     __shared__ int sidx[kInvThreads / 64];
     __shared__ int s_p;
     const NdDevNode nd = nodes[list[blockIdx.x]];
     const int p = nd.np, ld = nd.np + nd.nu;
-    if (p > kNdSmallPivot) return;
-    double *__restrict__ M = fronts + nd.foff;
+    if (p > kNdTinyPivot) return;
+    const int lm = p + 1;  // odd-ish row pitch: column walks do not hit one bank
+    const double *__restrict__ F = fronts + nd.foff;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int e = tid; e < p * p; e += kInvThreads) M[(e / p) * lm + e % p] = F[(size_t)(e / p) * ld + e % p];
+    __syncthreads();
     for (int k = 0; k < p; ++k) {
         double best = -1.0;
         int bi = k;
-        {
-            const int i = k + tid;  // p <= kInvThreads: one candidate per thread
-            if (i < p) {
-                best = fabs(M[(size_t)i * ld + k]);
+        for (int i = k + tid; i < p; i += kInvThreads) {
+            const double m = fabs(M[i * lm + k]);
+            if (m > best) {
+                best = m;
                 bi = i;
             }
         }
@@ -109,25 +113,21 @@ __global__ __launch_bounds__(kInvThreads) void nd_invert_kernel(const NdDevNode 
         const int pv = s_p;
         if (pv != k)
             for (int j = tid; j < p; j += kInvThreads) {
-                const double a = M[(size_t)k * ld + j], b = M[(size_t)pv * ld + j];
-                M[(size_t)k * ld + j] = b;
-                M[(size_t)pv * ld + j] = a;
+                const double a = M[k * lm + j], b = M[pv * lm + j];
+                M[k * lm + j] = b;
+                M[pv * lm + j] = a;
             }
         __syncthreads();
-        const double rpiv = 1.0 / M[(size_t)k * ld + k];
+        const double rpiv = 1.0 / M[k * lm + k];
         for (int j = tid; j < p; j += kInvThreads) {
-            prow[j] = (j == k) ? rpiv : M[(size_t)k * ld + j] * rpiv;
-            fcol[j] = M[(size_t)j * ld + k];
+            prow[j] = (j == k) ? rpiv : M[k * lm + j] * rpiv;
+            fcol[j] = M[j * lm + k];
         }
         __syncthreads();
-        for (int i = wv; i < p; i += kInvThreads / 64) {
-            double *__restrict__ row = M + (size_t)i * ld;
-            if (i == k) {
-                for (int j = lane; j < p; j += 64) row[j] = prow[j];
-            } else {
-                const double f = fcol[i];
-                for (int j = lane; j < p; j += 64) row[j] = (j == k) ? -f * rpiv : row[j] - f * prow[j];
-            }
+        for (int e = tid; e < p * p; e += kInvThreads) {
+            const int i = e / p, j = e % p;
+            double *m = &M[i * lm + j];
+            *m = (i == k) ? prow[j] : ((j == k) ? -fcol[i] * rpiv : *m - fcol[i] * prow[j]);
         }
         __syncthreads();
     }
@@ -142,8 +142,136 @@ __global__ __launch_bounds__(kInvThreads) void nd_invert_kernel(const NdDevNode 
         }
     __syncthreads();
     double *__restrict__ out = Bm + nd.boff;
-    for (int i = wv; i < p; i += kInvThreads / 64)
-        for (int j = lane; j < p; j += 64) out[(size_t)i * ld + j] = M[(size_t)i * ld + cm[j]];
+    for (int e = tid; e < p * p; e += kInvThreads) out[(size_t)(e / p) * ld + e % p] = M[(e / p) * lm + cm[e % p]];
+}
+
+// ---- pivot blocks above kNdTinyPivot rows: Gauss-Jordan with partial pivoting spread over the whole chip, ALL such nodes of a
+// tree level in the same launches -- one launch per pivot step (the same scheme as bt_gj_kernel of coarse_kernels.hip, batched):
+// out of place between two buffers per node (so no workgroup reads what another one writes in the same launch), every workgroup
+// finds the step's pivot itself from the column magnitudes the previous step left, the scaled pivot row sits in LDS.
+//   p = argmax_{i >= k} |src[i][k]| (lowest index on ties)
+//   dst[k] = src[p] / piv, dst[k][k] = 1 / piv ; dst[i] = src[s] - f dst[k], dst[i][k] = -f / piv  (s = i == p ? k : i, f = src[s][k])
+constexpr int kGjRowsPerWg = 8;
+
+__global__ __launch_bounds__(kNB) void nd_gj_col0_kernel(const NdGjNode *__restrict__ nodes, const int *__restrict__ wg_node)
+{
+    const NdGjNode nd = nodes[wg_node[blockIdx.x]];
+    const int i0 = ((int)blockIdx.x - nd.wg0) * kGjRowsPerWg;
+    for (int q = threadIdx.x; q < kGjRowsPerWg; q += kNB) {
+        const int i = i0 + q;
+        if (i < nd.p) nd.c0[i] = fabs(nd.a[(size_t)i * nd.lda]);
+    }
+}
+
+__global__ __launch_bounds__(kNB) void nd_gj_step_kernel(const NdGjNode *__restrict__ nodes, const int *__restrict__ wg_node, int k,
+                                                         int *__restrict__ singular)
+{
+    extern __shared__ double prow[];
+    __shared__ double smax[kNB / 64];
+    __shared__ int sidx[kNB / 64];
+    __shared__ int s_p;
+    const NdGjNode nd = nodes[wg_node[blockIdx.x]];
+    const int bs = nd.p;
+    if (k >= bs) return;  // (workgroup-uniform) this node is done
+    const bool odd = k & 1;
+    const double *__restrict__ src = odd ? nd.b : nd.a;
+    double *__restrict__ dst = odd ? nd.a : nd.b;
+    const int lds = odd ? nd.ldb : nd.lda, ldd = odd ? nd.lda : nd.ldb;
+    const double *__restrict__ colcur = odd ? nd.c1 : nd.c0;
+    double *__restrict__ colnext = odd ? nd.c0 : nd.c1;
+    double best = -1.0;
+    int bi = k;
+    for (int i = k + threadIdx.x; i < bs; i += kNB) {
+        const double m = colcur[i];
+        if (m > best) {
+            best = m;
+            bi = i;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_down(best, off, 64);
+        const int oi = __shfl_down(bi, off, 64);
+        if (ob > best || (ob == best && oi < bi)) {
+            best = ob;
+            bi = oi;
+        }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        smax[w] = best;
+        sidx[w] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double b = smax[0];
+        int ix = sidx[0];
+        for (int q = 1; q < kNB / 64; ++q)
+            if (smax[q] > b || (smax[q] == b && sidx[q] < ix)) {
+                b = smax[q];
+                ix = sidx[q];
+            }
+        s_p = ix;
+        if ((int)blockIdx.x == nd.wg0) {
+            nd.piv[k] = ix;
+            if (!(b > 0.0)) *singular = 1;
+        }
+    }
+    __syncthreads();
+    const int p = s_p;
+    const double rpiv = 1.0 / src[(size_t)p * lds + k];
+    const double *__restrict__ sp = src + (size_t)p * lds;
+    for (int j = threadIdx.x; j < bs; j += kNB) prow[j] = (j == k) ? rpiv : sp[j] * rpiv;
+    __syncthreads();
+    const int i0 = ((int)blockIdx.x - nd.wg0) * kGjRowsPerWg;
+#pragma unroll 1
+    for (int q = 0; q < kGjRowsPerWg; ++q) {
+        const int i = i0 + q;
+        if (i >= bs) break;
+        double *__restrict__ d = dst + (size_t)i * ldd;
+        if (i == k) {
+            for (int j = threadIdx.x; j < bs; j += kNB) d[j] = prow[j];
+            continue;
+        }
+        const int sr_i = (i == p) ? k : i;
+        const double *__restrict__ sr = src + (size_t)sr_i * lds;
+        const double f = sr[k];
+        for (int j = threadIdx.x; j < bs; j += kNB) {
+            const double nv = (j == k) ? -f * rpiv : sr[j] - f * prow[j];
+            d[j] = nv;
+            if (j == k + 1) colnext[i] = fabs(nv);
+        }
+    }
+}
+
+// (PA)^-1 = A^-1 P^-1: the columns are swapped back in reverse pivot order.  One workgroup per node builds the column map ...
+__global__ __launch_bounds__(kNB) void nd_gj_colmap_kernel(const NdGjNode *__restrict__ nodes)
+{
+    const NdGjNode nd = nodes[blockIdx.x];
+    for (int j = threadIdx.x; j < nd.p; j += kNB) nd.cmap[j] = j;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = nd.p - 1; k >= 0; --k) {
+            const int q = nd.piv[k];
+            const int t = nd.cmap[k];
+            nd.cmap[k] = nd.cmap[q];
+            nd.cmap[q] = t;
+        }
+}
+
+// ... and all rows copy through it into B_k (the buffer the last step wrote: a for an even number of steps, b for an odd one)
+__global__ __launch_bounds__(kNB) void nd_gj_unscramble_kernel(const NdGjNode *__restrict__ nodes, const int *__restrict__ wg_node)
+{
+    const NdGjNode nd = nodes[wg_node[blockIdx.x]];
+    const bool in_b = nd.p & 1;
+    const double *__restrict__ R = in_b ? nd.b : nd.a;
+    const int ldr = in_b ? nd.ldb : nd.lda;
+    const int i0 = ((int)blockIdx.x - nd.wg0) * kGjRowsPerWg;
+    for (int q = 0; q < kGjRowsPerWg; ++q) {
+        const int i = i0 + q;
+        if (i >= nd.p) break;
+        for (int j = threadIdx.x; j < nd.p; j += kNB) nd.out[(size_t)i * nd.ldo + j] = R[(size_t)i * ldr + nd.cmap[j]];
+    }
 }
 
 __global__ __launch_bounds__(kNB) void nd_copy_block_kernel(const double *__restrict__ src, int lds, double *__restrict__ dst, int ldd, int rows,
@@ -300,10 +428,19 @@ void nd_launch_extend_add(const NdDevNode *nodes, const int *children, int nchil
     hipLaunchKernelGGL(nd_extend_add_kernel, dim3(nchildren, (max_nu + kNB / 64 - 1) / (kNB / 64)), dim3(kNB), 0, st, nodes, children, rel_idx, fronts);
 }
 
-void nd_launch_invert(const NdDevNode *nodes, const int *list, int count, double *fronts, double *Bm, int *singular, hipStream_t st)
+void nd_launch_invert(const NdDevNode *nodes, const int *list, int count, const double *fronts, double *Bm, int *singular, hipStream_t st)
 {
     if (count <= 0) return;
     hipLaunchKernelGGL(nd_invert_kernel, dim3(count), dim3(kInvThreads), 0, st, nodes, list, fronts, Bm, singular);
+}
+
+void nd_launch_gj_batched(const NdGjNode *nodes, int nnodes, const int *wg_node, int nwg, int max_p, int *singular, hipStream_t st)
+{
+    if (nnodes <= 0 || nwg <= 0) return;
+    hipLaunchKernelGGL(nd_gj_col0_kernel, dim3(nwg), dim3(kNB), 0, st, nodes, wg_node);
+    for (int k = 0; k < max_p; ++k) hipLaunchKernelGGL(nd_gj_step_kernel, dim3(nwg), dim3(kNB), (size_t)max_p * sizeof(double), st, nodes, wg_node, k, singular);
+    hipLaunchKernelGGL(nd_gj_colmap_kernel, dim3(nnodes), dim3(kNB), 0, st, nodes);
+    hipLaunchKernelGGL(nd_gj_unscramble_kernel, dim3(nwg), dim3(kNB), 0, st, nodes, wg_node);
 }
 
 void nd_launch_copy_block(const double *src, int lds, double *dst, int ldd, int rows, int cols, hipStream_t st)

@@ -128,19 +128,25 @@ bool NdSolver::setup(const HostCsr &A, const NdParams &prm, hipStream_t st, std:
     (void)hipMemsetAsync(fronts, 0, P.front_doubles * sizeof(double), st);
     (void)hipMemsetAsync(sing, 0, sizeof(int), st);
     nd_launch_scatter((long long)P.a_dst.size(), a_dst, a_val, fronts, st);
-    // scratch of the whole-chip inversion for pivot blocks above kNdSmallPivot rows
-    double *S2 = nullptr, *c0 = nullptr, *c1 = nullptr;
-    int *piv = nullptr, *cmap = nullptr;
-    if (P.max_np > kNdSmallPivot) {
-        size_t big = 0;
-        for (const NdNode &nd : P.nodes)
-            if (nd.np > kNdSmallPivot) big = std::max(big, (size_t)nd.np * (nd.np + nd.nu));
-        S2 = nd_alloc<double>(tmp, big, err);
-        c0 = nd_alloc<double>(tmp, (size_t)P.max_np, err);
-        c1 = nd_alloc<double>(tmp, (size_t)P.max_np, err);
-        piv = nd_alloc<int>(tmp, (size_t)P.max_np, err);
-        cmap = nd_alloc<int>(tmp, (size_t)P.max_np, err);
-        if (!(S2 && c0 && c1 && piv && cmap)) return fail();
+    // scratch of the batched whole-chip inversion (pivot blocks above kNdTinyPivot rows): per level the second buffers of its blocks
+    size_t gj_doubles = 0, gj_rows = 0;
+    for (int l = 0; l < P.nlevels; ++l) {
+        size_t d = 0, r = 0;
+        for (int k : P.level_nodes[l])
+            if (P.nodes[k].np > kNdTinyPivot) {
+                d += (size_t)P.nodes[k].np * P.nodes[k].np;
+                r += (size_t)P.nodes[k].np;
+            }
+        gj_doubles = std::max(gj_doubles, d);
+        gj_rows = std::max(gj_rows, r);
+    }
+    double *gj_buf = nullptr, *gj_col = nullptr;
+    int *gj_int = nullptr;
+    if (gj_rows > 0) {
+        gj_buf = nd_alloc<double>(tmp, gj_doubles, err);
+        gj_col = nd_alloc<double>(tmp, 2 * gj_rows, err);
+        gj_int = nd_alloc<int>(tmp, 2 * gj_rows, err);
+        if (!(gj_buf && gj_col && gj_int)) return fail();
     }
     const double t1 = now_s();
     // SPARSH_ND_TIMING=1: synchronise after every phase and print where the factorisation time goes
@@ -181,19 +187,49 @@ bool NdSolver::setup(const HostCsr &A, const NdParams &prm, hipStream_t st, std:
         lap(t_ext);
         // pivot-block inverses
         std::vector<int> small;
-        for (int k : ln)
-            if (P.nodes[k].np <= kNdSmallPivot) small.push_back(k);
+        std::vector<NdGjNode> big;
+        std::vector<int> wg_node;
+        {
+            size_t dpos = 0, rpos = 0;
+            for (int k : ln) {
+                const NdNode &nd = P.nodes[k];
+                if (nd.np <= kNdTinyPivot) {
+                    small.push_back(k);
+                    continue;
+                }
+                NdGjNode g;
+                g.a = fronts + nd.foff;
+                g.lda = nd.np + nd.nu;
+                g.b = gj_buf + dpos;
+                g.ldb = nd.np;
+                g.c0 = gj_col + 2 * rpos;
+                g.c1 = gj_col + 2 * rpos + nd.np;
+                g.piv = gj_int + 2 * rpos;
+                g.cmap = gj_int + 2 * rpos + nd.np;
+                g.out = Bm_ + nd.boff;
+                g.ldo = nd.np + nd.nu;
+                g.p = nd.np;
+                g.wg0 = (int)wg_node.size();
+                const int nwg = (nd.np + 7) / 8;
+                for (int q = 0; q < nwg; ++q) wg_node.push_back((int)big.size());
+                big.push_back(g);
+                dpos += (size_t)nd.np * nd.np;
+                rpos += (size_t)nd.np;
+            }
+        }
         if (!small.empty()) {
             int *sl = nd_upload(tmp, small, err);
             if (!sl) return fail();
             nd_launch_invert(nodes_, sl, (int)small.size(), fronts, Bm_, sing, st);
         }
         lap(t_inv);
-        for (int k : ln) {
-            const NdNode &nd = P.nodes[k];
-            if (nd.np <= kNdSmallPivot) continue;
-            const int ld = nd.np + nd.nu;
-            bt_launch_invert(nd.np, ld, fronts + nd.foff, S2, c0, c1, piv, cmap, sing, Bm_ + nd.boff, st);
+        if (!big.empty()) {
+            int max_p = 0;
+            for (const NdGjNode &g : big) max_p = std::max(max_p, g.p);
+            NdGjNode *bd = nd_upload(tmp, big, err);
+            int *wd = nd_upload(tmp, wg_node, err);
+            if (!bd || !wd) return fail();
+            nd_launch_gj_batched(bd, (int)big.size(), wd, (int)wg_node.size(), max_p, sing, st);
         }
         lap(t_big);
         // -D^-1 F12 -> B_k[:, np:], F21 D^-1 -> Lh_k ; then F22 += F21 (-D^-1 F12)

@@ -26,6 +26,14 @@ struct NdGemm {  // C (M x N) = alpha * A (M x K) * B (K x N) + (beta ? C : 0), 
     int beta, tiles_n;
 };
 
+struct NdGjNode {  // one pivot block of the batched whole-chip inversion (nd_kernels.hip)
+    double *a, *b;     // the block itself (in its front) and a scratch copy: the steps ping-pong between them
+    double *c0, *c1;   // column magnitudes for the pivot search, ping-pong
+    double *out;       // B_k
+    int *piv, *cmap;
+    int p, lda, ldb, ldo, wg0;  // wg0: first workgroup of this node in the launch
+};
+
 class NdSolver {
 public:
     ~NdSolver() { release(); }
@@ -68,12 +76,14 @@ private:
 // launchers of nd_kernels.hip
 void nd_launch_scatter(long long cnt, const long long *dst, const double *val, double *fronts, hipStream_t st);
 void nd_launch_extend_add(const NdDevNode *nodes, const int *children, int nchildren, int max_nu, const int *rel_idx, double *fronts, hipStream_t st);
-void nd_launch_invert(const NdDevNode *nodes, const int *list, int count, double *fronts, double *Bm, int *singular, hipStream_t st);
+void nd_launch_invert(const NdDevNode *nodes, const int *list, int count, const double *fronts, double *Bm, int *singular, hipStream_t st);
+void nd_launch_gj_batched(const NdGjNode *nodes, int nnodes, const int *wg_node, int nwg, int max_p, int *singular, hipStream_t st);
 void nd_launch_copy_block(const double *src, int lds, double *dst, int ldd, int rows, int cols, hipStream_t st);
 void nd_launch_gemm(const NdGemm *problems, const int *tiles, int ntiles, hipStream_t st);
 void nd_launch_repack(long long nseg, const NdSegment *segs, const double *Lh, double *Lf, hipStream_t st);
 void nd_launch_pass(bool forward, const NdRow *rows, int nrows, int nwide, int n, const double *M, const int *idx, double *w, const double *b, double *x,
                     hipStream_t st);
-constexpr int kNdSmallPivot = 1024;  // largest pivot block the one-workgroup inversion takes
+constexpr int kNdTinyPivot = 80;     // pivot blocks up to this many rows are inverted by one workgroup in LDS (80 x 81 doubles = 51 KB);
+                                     // larger ones by the batched whole-chip inversion
 
 }  // namespace sparsh

@@ -322,12 +322,14 @@ def test_config1_full_size_properties(form):
         h, rc = A.solve("pcg", b, x)
         assert rc == 0 and h[-1] <= 1e-8 and len(h) < 60 and np.all(np.diff(np.log(h)) < 0.7)
         true_r = np.linalg.norm(b - S @ x)
+        # CG tracks the residual by recurrence (as the reference does): the true one differs by O(eps ||A|| ||x||), and ||x|| ~ 7e7 here
+        # (b = 1 on a 1000^2 Laplacian): measured 5.5e-8 against 7.0e-9 on the recurrence
         assert abs(true_r - h[-1]) <= 100 * np.finfo(float).eps * 8.0 * np.linalg.norm(x)
-        assert true_r <= 5e-8
+        assert true_r <= 2e-7
         # stand-alone AMG V(7,7) cycles (AMG_Solver_CPU_baseline) converge too
         xa = np.zeros(n)
         ha, rca = A.solve("amg", b, xa)
-        assert rca == 0 and ha[-1] <= 1e-8 and np.linalg.norm(b - S @ xa) <= 5e-8
+        assert rca == 0 and ha[-1] <= 1e-8 and np.linalg.norm(b - S @ xa) <= 2e-7
         # the coarsest-level solve itself: residual of A_L x = b_L through the level's own SpMV
         L = A.nlevels - 1
         rng = np.random.default_rng(0)

@@ -409,3 +409,69 @@ def test_deep_halo_local_operator_every_family_every_prefix():
     assert not any(t.is_alive() for t in ts) and not errs, errs
     sa.comm_group_destroy(group)
     assert any("sdia_tab_kernel" in s for s in seen)
+
+
+def _tuned_run(rp, ci, v, b, G, delay_us, **kw):
+    """G virtual ranks with the measured schedule (replicate_rows = 0) over a transport whose every call costs delay_us more."""
+    group = sa.comm_group_create(G)
+    sa.comm_group_set_delay(group, delay_us)
+    out = [None] * G
+    errs = []
+
+    def work(r):
+        try:
+            A = sa.sp_matrix_mg(rp, ci, v)
+            A.comm_init_group(group, r)
+            A.setup(sa.default_params(**QUIET, replicate_rows=0, **kw))
+            lo, hi, _ = A.local_range(0)
+            x = np.zeros(hi - lo)
+            A.vcycle(b[lo:hi].copy(), x, iterations=3)
+            out[r] = (lo, x, A.comm_schedule(), A.comm_measured(), [A.local_range(l)[2] for l in range(A.nlevels)])
+            A.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in ts), "a virtual rank hung"
+    assert not errs, errs
+    sa.comm_group_destroy(group)
+    return out
+
+
+def test_measured_schedule_moves_with_the_transport_and_keeps_the_bits():
+    """the multi-rank schedule is chosen from measurements, not constants.  Two virtual ranks on one GPU, the
+    in-process transport once as it is (a device copy: a few microseconds per call) and once with 400 us added to every call (a slow
+    link).  The tuner must see the difference (measured exchange / all-reduce / all-gather times), replicate more levels over the
+    slow link than over the fast one, never choose the exchange-per-sweep schedule on the slow link, hand every rank the same
+    table -- and whatever it chooses, three V-cycles give the single-rank iterate bit for bit."""
+    rp, ci, v = problems.poisson3d(64)  # 262 144 rows
+    n = len(rp) - 1
+    b = np.random.default_rng(7).standard_normal(n)
+    A1 = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET))
+    x1 = np.zeros(n)
+    A1.vcycle(b, x1, iterations=3)
+    A1.close()
+    G = 2
+    fast = _tuned_run(rp, ci, v, b, G, 0.0)
+    slow = _tuned_run(rp, ci, v, b, G, 400.0)
+    for res in (fast, slow):
+        assert all(r[2] is not None and r[3] is not None for r in res)
+        assert all(r[2] == res[0][2] and r[3] == res[0][3] for r in res), "ranks disagree on the schedule"
+        x = np.concatenate([r[1] for r in sorted(res, key=lambda t: t[0])]) if not res[0][4][0] else res[0][1]
+        assert np.array_equal(x, x1)
+        # the table says what the engine then did
+        assert [c["partitioned"] for c in res[0][2]] == [not rep for rep in res[0][4]]
+    mf, ms = fast[0][3], slow[0][3]
+    assert ms["exchange_us"] >= mf["exchange_us"] + 300 and ms["allreduce_us"] >= mf["allreduce_us"] + 300 and ms["allgather_us"] >= mf["allgather_us"] + 300
+    nf = sum(c["partitioned"] for c in fast[0][2])
+    ns = sum(c["partitioned"] for c in slow[0][2])
+    assert ns <= nf, (nf, ns)
+    for c in slow[0][2]:
+        if c["partitioned"]:
+            assert c["deep_halo"] and c["model_us_deep_halo"] < c["model_us_exchange_per_sweep"]
+    # over a 400 us link a 262 144-row problem is cheaper replicated than partitioned over two ranks (the whole V-cycle is ~1 ms)
+    assert ns == 0, slow[0][2]
