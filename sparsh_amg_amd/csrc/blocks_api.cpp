@@ -326,8 +326,8 @@ Direct_Solver_Pardiso::Direct_Solver_Pardiso(sp_matrix_mg &A)
             std::exit(1);  // the reference exits on a PARDISO error (src/AMG_coarse_level_solver.cpp:53-57)
         }
         ok = d->solver.setup_dense(n, inv.data(), err);
-    } else {  // block-tridiagonal factors, built on the device
-        ok = d->solver.setup_bt(H, nullptr, err);
+    } else {  // nested-dissection multifrontal factors, built on the device (what PARDISO does on the host in the reference)
+        ok = d->solver.setup_nd(H, nullptr, err);
     }
     if (!ok) {
         std::cout << "sparsh: coarse direct solver failed (" << err << "); without a HIP device there is no CPU fallback" << std::endl;

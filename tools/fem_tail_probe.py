@@ -16,5 +16,5 @@ for npts in [int(a) for a in sys.argv[1:]] or [480000, 505000, 515000, 520000, 5
     ja = A.bench_op("jacobi", 0, 50) * 1e6
     nnz = int(rp[-1])
     nblk = A.level_index16(0)[1]
-    print(f"rows {n:7d} nnz {nnz:8d} row blocks {nblk:5d} kernel {A.level_kernel(0)}: spmv {sp:6.2f} us ({(12*nnz+20*n)/sp/1e6:6.0f} GB/s)  jacobi {ja:6.2f} us ({(12*nnz+36*n)/ja/1e6:6.0f} GB/s)", flush=True)
+    print(f"rows {n:7d} nnz {nnz:8d} row blocks {nblk:5d} kernel {A.level_kernel(0)}: spmv {sp:6.2f} us ({(12*nnz+20*n)/sp/1e3:6.0f} GB/s)  jacobi {ja:6.2f} us ({(12*nnz+36*n)/ja/1e3:6.0f} GB/s)", flush=True)
     A.close()
