@@ -628,7 +628,8 @@ def test_config4_iteration_count_band_is_backed_by_the_oracles_own_sensitivity(c
     x = np.zeros(A.nrow)
     h, rc = A.solve("pbicg", b, x)
     assert rc == 0 and 0.75 * lo <= len(h) <= 1.25 * hi, (len(h), counts)
-    assert np.linalg.norm(b - S @ x) <= 1.001e-8
+    # (recurrence residual at tol, true residual within a factor 1.5 of it: see test_config4_full_size_bicgstab_converges)
+    assert h[-1] <= 1e-8 and np.linalg.norm(b - S @ x) <= 1.5e-8
 
 
 def test_config4_full_size_breakdown_like_the_oracle(config4_full):
