@@ -73,11 +73,11 @@ def main():
     if want("C2D_poisson2d_1000"):
         res["C2D_poisson2d_1000"] = run("C2D", *problems.poisson2d(1000), ["amg", "pcg"])  # default: the reference's 6 levels + block-tridiagonal direct solve
     if want("C2D_poisson2d_1000_extended_hierarchy"):
-        res["C2D_poisson2d_1000_extended_hierarchy"] = run("C2D ext", *problems.poisson2d(1000), ["amg", "pcg"], coarse_limit=8192)
+        res["C2D_poisson2d_1000_extended_hierarchy"] = run("C2D ext", *problems.poisson2d(1000), ["amg", "pcg"], coarse_limit=8192, extend_until=4000)
     if want("C3D_poisson3d_100"):
         res["C3D_poisson3d_100"] = run("100^3", *problems.poisson3d(100), ["amg", "pcg"])
     if want("C3D_poisson3d_100_extended_hierarchy"):
-        res["C3D_poisson3d_100_extended_hierarchy"] = run("100^3 ext", *problems.poisson3d(100), ["amg", "pcg"], coarse_limit=8192)
+        res["C3D_poisson3d_100_extended_hierarchy"] = run("100^3 ext", *problems.poisson3d(100), ["amg", "pcg"], coarse_limit=8192, extend_until=4000)
     # the reference's own 6-level policy one size further than the default coarse_limit allows: 136^3 leaves a
     # 78 608-row coarsest level; next to it the default (hierarchy extended until <= 40 000 rows)
     if want("C3D_poisson3d_136_reference_policy"):
