@@ -383,6 +383,9 @@ int sparsh_comm_init_group(sparsh_handle h, void *group, int rank);
  * sparsh_comm_group_set_delay (in-process test transport only): every transport call occupies the caller's stream that many
  * microseconds first -- a slow link, to see the schedule move. */
 int sparsh_set_comm_tuning(sparsh_handle h, int mode);
+/* host-only what-if (after sparsh_setup_host; no device, no transport): the schedule the tuner would choose for `nranks` ranks from the
+ * seven numbers m7 (layout of sparsh_comm_measured); read it back with sparsh_comm_schedule */
+int sparsh_plan_comm_schedule(sparsh_handle h, int nranks, const double *m7);
 int sparsh_comm_schedule(sparsh_handle h, int level, int *info4, double *cost_us3);
 int sparsh_comm_measured(sparsh_handle h, double *m7);
 int sparsh_comm_group_set_delay(void *group, double microseconds);

@@ -137,6 +137,7 @@ def _load():
         "sparsh_set_comm_tuning": (C.c_int, [H, C.c_int]),
         "sparsh_comm_schedule": (C.c_int, [H, C.c_int, c_int_p, c_dbl_p]),
         "sparsh_comm_measured": (C.c_int, [H, c_dbl_p]),
+        "sparsh_plan_comm_schedule": (C.c_int, [H, C.c_int, c_dbl_p]),
         "sparsh_comm_init_group": (C.c_int, [H, C.c_void_p, C.c_int]),
         "sparsh_dist_local_op": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p]),
         "sparsh_dist_local_op_get": (C.c_int, [H, c_int_p, c_int_p, c_dbl_p, c_int_p, c_int_p, c_int_p, c_int_p]),
@@ -476,6 +477,12 @@ class sp_matrix_mg:
             out.append({"level": l, "rows": info[0], "boundary_rows": info[1], "partitioned": bool(info[2]), "deep_halo": bool(info[3]),
                         "model_us_deep_halo": round(cost[0], 2), "model_us_exchange_per_sweep": round(cost[1], 2), "model_us_replicated": round(cost[2], 2)})
         return out
+
+    def plan_comm_schedule(self, nranks, exchange_us, exchange_us_per_MB, allreduce_us, allgather_us, allgather_us_per_MB, sweep_floor_us, sweep_us_per_MB):
+        """Host-only what-if: the schedule the tuner would choose for `nranks` ranks from these measurements (no device, no transport)."""
+        m = (C.c_double * 7)(exchange_us, exchange_us_per_MB, allreduce_us, allgather_us, allgather_us_per_MB, sweep_floor_us, sweep_us_per_MB)
+        _check(lib.sparsh_plan_comm_schedule(self._h, int(nranks), m))
+        return self.comm_schedule()
 
     def comm_measured(self):
         m = (C.c_double * 7)()

@@ -641,10 +641,26 @@ int sparsh_set_comm_tuning(sparsh_handle h, int mode)
     return SPARSH_OK;
 }
 
+int sparsh_plan_comm_schedule(sparsh_handle h, int nranks, const double *m7)
+{
+    REQUIRE_HOST(h);
+    if (nranks < 2 || !m7) return fail(SPARSH_EINVAL, "nranks >= 2 and seven measured numbers are needed");
+    Engine::CommMeasured m;
+    m.exchange_us = m7[0];
+    m.exchange_us_per_mb = m7[1];
+    m.allreduce_us = m7[2];
+    m.allgather_us = m7[3];
+    m.allgather_us_per_mb = m7[4];
+    m.sweep_floor_us = m7[5];
+    m.sweep_us_per_mb = m7[6];
+    h->eng->plan_comm_schedule(h->eng->params(), nranks, m);
+    return SPARSH_OK;
+}
+
 int sparsh_comm_schedule(sparsh_handle h, int level, int *info4, double *cost_us3)
 {
-    REQUIRE_READY(h);
-    REQUIRE_LEVEL(h, level);
+    REQUIRE_HOST(h);
+    if (level < 0 || level >= (int)h->eng->host().levels.size()) return fail(SPARSH_EINVAL, "level out of range");
     const auto &sc = h->eng->comm_schedule();
     if (sc.empty()) return fail(SPARSH_ESTATE, "no measured schedule: one rank, tuning off, or replicate_rows given by the caller");
     const auto &c = sc[level];
@@ -664,7 +680,7 @@ int sparsh_comm_schedule(sparsh_handle h, int level, int *info4, double *cost_us
 
 int sparsh_comm_measured(sparsh_handle h, double *m7)
 {
-    REQUIRE_READY(h);
+    REQUIRE_HOST(h);
     const auto &m = h->eng->comm_measured();
     if (!m.valid) return fail(SPARSH_ESTATE, "the transport was not measured in this setup");
     if (m7) {

@@ -926,9 +926,21 @@ bool Engine::measure_transport()
 
 void Engine::tune_comm_schedule(const sparsh_params &p)
 {
-    const int G = comm_->size;
+    if (comm_->size <= 1 || H_.levels.size() < 2 || !measure_transport()) return;
+    decide_comm_schedule(p, comm_->size);
+    if (p.print_setup && comm_->rank == 0) {
+        std::printf("transport measured: exchange %.1f us + %.2f us/MB, all-reduce %.1f us, all-gather %.1f us + %.2f us/MB; device sweep floor %.1f us, %.2f us/MB\n",
+                    meas_.exchange_us, meas_.exchange_us_per_mb, meas_.allreduce_us, meas_.allgather_us, meas_.allgather_us_per_mb, meas_.sweep_floor_us, meas_.sweep_us_per_mb);
+        std::printf("schedule: %d of %d levels partitioned over %d ranks, %s\n", tuned_repl_level_, (int)H_.levels.size(), comm_->size,
+                    tuned_repl_level_ == 0 ? "everything replicated" : (tuned_deep_ ? "deep-halo smoothing" : "one exchange per sweep"));
+    }
+}
+
+// the decision alone: pure host arithmetic on the hierarchy and on meas_ (also reachable without a device: sparsh_plan_comm_schedule)
+void Engine::decide_comm_schedule(const sparsh_params &p, int G)
+{
     const int nl = (int)H_.levels.size();
-    if (G <= 1 || nl < 2 || !measure_transport()) return;
+    if (G <= 1 || nl < 2 || !meas_.valid) return;
     const double mb = 1.0 / 1048576.0;
     const int nu = std::max(1, p.sweeps);
     auto sweep_us = [&](double rows, double bpr) { return meas_.sweep_floor_us + rows * bpr * mb * meas_.sweep_us_per_mb; };
@@ -981,11 +993,6 @@ void Engine::tune_comm_schedule(const sparsh_params &p)
     for (int l = 0; l < nl; ++l) {
         sched_[l].partitioned = l < best_lr;
         sched_[l].deep = l < best_lr && best_deep;
-    }
-    if (p.print_setup && comm_->rank == 0) {
-        std::printf("transport measured: exchange %.1f us + %.2f us/MB, all-reduce %.1f us, all-gather %.1f us + %.2f us/MB; device sweep floor %.1f us, %.2f us/MB\n",
-                    meas_.exchange_us, meas_.exchange_us_per_mb, meas_.allreduce_us, meas_.allgather_us, meas_.allgather_us_per_mb, meas_.sweep_floor_us, meas_.sweep_us_per_mb);
-        std::printf("schedule: %d of %d levels partitioned over %d ranks, %s\n", best_lr, nl, G, best_lr == 0 ? "everything replicated" : (best_deep ? "deep-halo smoothing" : "one exchange per sweep"));
     }
 }
 

@@ -129,6 +129,16 @@ public:
         double sweep_floor_us = 0.0, sweep_us_per_mb = 0.0;
         bool valid = false;
     };
+    // host-only: the schedule the tuner would choose for `nranks` ranks from the given measurements (tests, what-if tables)
+    void plan_comm_schedule(const sparsh_params &p, int nranks, const CommMeasured &m)
+    {
+        meas_ = m;
+        meas_.valid = true;
+        sched_.clear();
+        tuned_repl_level_ = -1;
+        decide_comm_schedule(p, nranks);
+    }
+    int tuned_partitioned_levels() const { return tuned_repl_level_; }
     const std::vector<CommLevelChoice> &comm_schedule() const { return sched_; }
     const CommMeasured &comm_measured() const { return meas_; }
     long exchanges_issued() const { return n_exchanges_; }
@@ -236,6 +246,7 @@ private:
     CommMeasured meas_;
     bool measure_transport();
     void tune_comm_schedule(const sparsh_params &p);
+    void decide_comm_schedule(const sparsh_params &p, int G);
     long n_exchanges_ = 0;          // transport calls issued (halo / staged exchanges; diagnostics)
     hipStream_t st2_ = nullptr;     // exchange stream of the overlap path
     hipEvent_t ev_ready_ = nullptr, ev_halo_ = nullptr;

@@ -264,3 +264,37 @@ def test_reference_level_policy_is_the_default():
     assert info["rows"] == 31250 and not info["dense"] and not info["extended"]
     with pytest.raises(sa.SparshError):
         A.coarse_inverse()  # no dense inverse above dense_limit
+
+
+def test_multi_rank_schedule_decision_follows_the_measured_transport():
+    """The decision half of the multi-rank tuner (Engine::decide_comm_schedule) without a device: a variable-coefficient 100^3
+    operator (8 B per entry streamed: a sweep over 1 M rows costs ~20 us on one GPU) on 8 ranks, from a free link to a hopeless one --
+    fewer levels stay partitioned as a transport call gets dearer, a link that costs more than a whole replicated V-cycle partitions
+    nothing, latency-bound links choose deep halos (4 exchanges per level and cycle instead of 16) and a link whose calls are free
+    chooses the exchange-per-sweep schedule (no redundant ghost-row sweeps).  On the constant-coefficient operator (25 B per row on the
+    table path: the same sweep costs 8 us) a 15 us link is not worth one partitioned level: round 2's replicate_rows = 1.5 M, derived."""
+    rp, ci, v = problems.poisson3d(100)
+    dev = dict(sweep_floor_us=3.3, sweep_us_per_MB=0.2)   # 5 TB/s
+    link = lambda lat: dict(exchange_us=lat, exchange_us_per_MB=10.0, allreduce_us=lat, allgather_us=2 * lat, allgather_us_per_MB=10.0)  # noqa: E731
+    vv = v * (1.0 + 0.1 * np.random.default_rng(0).random(len(v)))
+    A = sa.sp_matrix_mg(rp, ci, vv).setup(sa.default_params(print_setup=0, print_solve=0), host_only=True)
+    npart = []
+    for lat in (0.0, 5.0, 15.0, 100.0, 5000.0):
+        t = A.plan_comm_schedule(8, **link(lat), **dev)
+        assert t is not None and len(t) == A.nlevels and [c["rows"] for c in t] == [A.level_info(l)["nrow"] for l in range(A.nlevels)]
+        parts = [c["partitioned"] for c in t]
+        assert parts == sorted(parts, reverse=True) and not parts[-1]        # a prefix of levels; the coarsest one never
+        npart.append(sum(parts))
+        for c in t[:-1]:
+            assert c["boundary_rows"] > 0 and c["model_us_replicated"] > 0
+        if lat == 0.0:
+            assert npart[-1] >= 3 and not any(c["deep_halo"] for c in t)     # free exchanges: no reason to sweep ghost rows redundantly
+        if lat == 15.0:
+            assert npart[-1] >= 1 and all(c["deep_halo"] for c in t if c["partitioned"])
+            assert all(c["model_us_deep_halo"] < c["model_us_exchange_per_sweep"] for c in t[:-1])
+    assert npart == sorted(npart, reverse=True) and npart[-1] == 0, npart
+    A.close()
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, print_solve=0), host_only=True)
+    assert not any(c["partitioned"] for c in A.plan_comm_schedule(8, **link(15.0), **dev))
+    assert sum(c["partitioned"] for c in A.plan_comm_schedule(8, **link(0.0), **dev)) >= 3
+    A.close()
