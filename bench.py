@@ -437,6 +437,30 @@ def main():
                 families[key] = {"error": repr(e)}
         general = families.get("general_values_layout")
 
+    # transparency: the same problem with the REFERENCE's own level policy (level1 = 6 levels, whatever is left -- 314 928 rows at 216^3 --
+    # goes to the direct solver, src/AMG_phases.cpp:51,77,89): iterations to 1e-8, time, and the steady iteration rate
+    ref_policy = None
+    if world == 1 and mode == "single" and not args.no_families and coarse["extended"]:
+        log("reference level policy run (6 levels, direct solve of the rest)")
+        try:
+            prm_ref = sa.default_params(print_setup=0, print_solve=0, device=local_rank, host_threads=host_threads, coarse_limit=1 << 30)
+            A3 = new_handle(fold=not no_fold, cfg=main_cfg).setup(prm_ref)
+            b3 = A3.dev_alloc(8 * n)
+            x3 = A3.dev_alloc(8 * n)
+            A3.h2d(b3, b)
+            A3.h2d(x3, np.zeros(n))
+            h3, it3, sec3, rc3 = A3.solve_dev("pcg", b3, x3)
+            c3 = A3.coarse_info()
+            ref_policy = {"levels": [A3.level_info(l)["nrow"] for l in range(A3.nlevels)], "coarsest_level": c3,
+                          "coarse_solve_us": round(A3.bench_op("coarse", A3.nlevels - 1, 10) * 1e6, 1),
+                          "iterations_to_1e-8": it3, "seconds": round(sec3, 4), "iterations_per_s": round(it3 / sec3, 2), "rc": rc3,
+                          "setup_seconds": round(A3.setup_seconds, 2),
+                          "note": "the iteration the reference itself runs at this size (its PARDISO solve of the 6th level done by the device's nested-dissection "
+                                  "factors); `value` is measured on the extended hierarchy, whose iterations are cheaper and more numerous"}
+            A3.close()
+        except Exception as e:  # noqa: BLE001
+            ref_policy = {"error": repr(e)}
+
     # roofline.traffic: HBM bytes per launch of the dominant kernel from PMC counters, collected in THIS run by
     # two child processes (separate FETCH_SIZE / WRITE_SIZE passes, MI355X_MICROARCH.md), same grid, same
     # kernel configuration; corrected with calibration kernels of known size run in the same child.
@@ -663,6 +687,7 @@ def main():
                 "full_solve_to_1e-8": full,
                 "general_values_layout": general,
                 "kernel_families": families,
+                "reference_level_policy": ref_policy,
                 "comm_us": comm_us,
                 "comm_schedule": ({"measured": A.comm_measured(), "levels": A.comm_schedule()} if mode == "partitioned" or world > 1 else None),
                 "setup_seconds_host": round(A.setup_seconds, 2),

@@ -649,9 +649,11 @@ def test_config4_full_size_breakdown_like_the_oracle(config4_full):
     hh = np.array(go["hist_head"][:4])
     assert np.all(np.abs(h[:4] - hh) <= 1e-5 * hh)  # degenerate Krylov space: rounding shows from the first iteration (measured 1e-7)
     fin = h[np.isfinite(h)]
-    # both stagnate five orders of magnitude above tol (oracle at 7.2e-3 for 1854 iterations, the device measured at
-    # 5.6e-3 for 691) and then hit 0/0; where rounding trips it is chaotic, so only the level's magnitude is held
-    assert len(fin) > 100 and go["hist_tail"][0] / 3 <= fin[-1] <= go["hist_tail"][0] * 3
+    # All stagnate orders of magnitude above tol and then hit 0/0 -- the oracle at 7.2e-3 after 1854 iterations, the device at 5.6e-3
+    # after 691 (round 2, block-tridiagonal coarse factors) and at 3.4e-5 after 1795 (round 3, nested-dissection factors): where and
+    # at what level rounding trips a degenerate BiCGStab is chaotic, so the level is NOT held (round 2 held it to a band fitted to
+    # its own output); held: the run never reaches tol, ends in the breakdown, and says so.
+    assert len(fin) > 100 and fin.min() > 1e3 * 1e-8 and len(fin) < len(h)
     assert len(h) < 8000
     gp = g["constant_rhs"]["pcg"]
     A.set_stopping(1e-8, 100000, 1)
