@@ -274,14 +274,6 @@ __global__ __launch_bounds__(kNB) void nd_gj_unscramble_kernel(const NdGjNode *_
     }
 }
 
-__global__ __launch_bounds__(kNB) void nd_copy_block_kernel(const double *__restrict__ src, int lds, double *__restrict__ dst, int ldd, int rows,
-                                                            int cols)
-{
-    const int i = blockIdx.x;
-    if (i >= rows) return;
-    for (int j = threadIdx.x; j < cols; j += kNB) dst[(size_t)i * ldd + j] = src[(size_t)i * lds + j];
-}
-
 // batched GEMM, one 64 x 64 tile of one problem per workgroup, K in steps of 16 through LDS, 4 x 4 results per thread
 constexpr int kTM = 64, kTN = 64, kTK = 16;
 
@@ -441,12 +433,6 @@ void nd_launch_gj_batched(const NdGjNode *nodes, int nnodes, const int *wg_node,
     for (int k = 0; k < max_p; ++k) hipLaunchKernelGGL(nd_gj_step_kernel, dim3(nwg), dim3(kNB), (size_t)max_p * sizeof(double), st, nodes, wg_node, k, singular);
     hipLaunchKernelGGL(nd_gj_colmap_kernel, dim3(nnodes), dim3(kNB), 0, st, nodes);
     hipLaunchKernelGGL(nd_gj_unscramble_kernel, dim3(nwg), dim3(kNB), 0, st, nodes, wg_node);
-}
-
-void nd_launch_copy_block(const double *src, int lds, double *dst, int ldd, int rows, int cols, hipStream_t st)
-{
-    if (rows <= 0 || cols <= 0) return;
-    hipLaunchKernelGGL(nd_copy_block_kernel, dim3(rows), dim3(kNB), 0, st, src, lds, dst, ldd, rows, cols);
 }
 
 void nd_launch_gemm(const NdGemm *problems, const int *tiles, int ntiles, hipStream_t st)

@@ -151,20 +151,18 @@ bool NdSolver::setup(const HostCsr &A, const NdParams &prm, hipStream_t st, std:
     const double t1 = now_s();
     // SPARSH_ND_TIMING=1: synchronise after every phase and print where the factorisation time goes
     const bool timing = std::getenv("SPARSH_ND_TIMING") != nullptr;
-    double t_ext = 0.0, t_inv = 0.0, t_big = 0.0, t_gemm = 0.0;
-    auto lap = [&](double &acc) {
+    double t_ext = 0.0, t_inv = 0.0, t_big = 0.0, t_gemm = 0.0, t_last = 0.0;
+    auto lap = [&](double &acc) {  // time since the previous lap goes to `acc`
         if (!timing) return;
-        static thread_local double last = 0.0;
         (void)hipStreamSynchronize(st);
         const double t = now_s();
-        if (&acc != &t_ext || last != 0.0) acc += t - last;
-        last = t;
+        acc += t - t_last;
+        t_last = t;
     };
     if (timing) {
         (void)hipStreamSynchronize(st);
-        std::printf("nd timing: plan %.3f s, uploads + scatter %.3f s\n", plan_seconds, now_s() - t_up);
-        double dummy = 0.0;
-        lap(dummy);
+        t_last = now_s();
+        std::printf("nd timing: plan %.3f s, uploads + scatter %.3f s\n", plan_seconds, t_last - t_up);
     }
     for (int l = 0; l < P.nlevels; ++l) {
         const std::vector<int> &ln = P.level_nodes[l];

@@ -78,7 +78,6 @@ void nd_launch_scatter(long long cnt, const long long *dst, const double *val, d
 void nd_launch_extend_add(const NdDevNode *nodes, const int *children, int nchildren, int max_nu, const int *rel_idx, double *fronts, hipStream_t st);
 void nd_launch_invert(const NdDevNode *nodes, const int *list, int count, const double *fronts, double *Bm, int *singular, hipStream_t st);
 void nd_launch_gj_batched(const NdGjNode *nodes, int nnodes, const int *wg_node, int nwg, int max_p, int *singular, hipStream_t st);
-void nd_launch_copy_block(const double *src, int lds, double *dst, int ldd, int rows, int cols, hipStream_t st);
 void nd_launch_gemm(const NdGemm *problems, const int *tiles, int ntiles, hipStream_t st);
 void nd_launch_repack(long long nseg, const NdSegment *segs, const double *Lh, double *Lf, hipStream_t st);
 void nd_launch_pass(bool forward, const NdRow *rows, int nrows, int nwide, int n, const double *M, const int *idx, double *w, const double *b, double *x,
