@@ -95,8 +95,11 @@ def main():
         import torch
         import torch.distributed as dist_mod
 
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # (local_rank % device count: several ranks may share a GPU -- a development aid to exercise the RCCL path on a one-GPU box,
+        # where RCCL allows it; never used by the driver, which gives every rank a GPU of its own)
+        dev_index = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(dev_index)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         dist = dist_mod
 
     # Multi-GPU insurance: the partitioned path (RCCL halo exchange) cannot be exercised with N >= 2 on the one-GPU boxes this
@@ -161,7 +164,7 @@ def main():
         # independent replicas, and the record says so.
         ok, err = 1, ""
         try:
-            sa.set_device(local_rank)
+            sa.set_device(local_rank % max(1, sa.device_count()))
             uid = [sa.comm_unique_id() if rank == 0 else None]
             if dist is not None:
                 dist.broadcast_object_list(uid, src=0)
