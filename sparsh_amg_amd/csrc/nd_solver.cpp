@@ -285,7 +285,9 @@ bool NdSolver::setup(const HostCsr &A, const NdParams &prm, hipStream_t st, std:
     nnodes_ = nn;
     leaf_ = P.leaf;
     max_np_ = P.max_np;
-    factor_bytes_ = P.factor_bytes();
+    // everything a solve streams: the factor rows, their gather indices (one int32 per forward element, one list per node for the
+    // backward pass) and the row records
+    factor_bytes_ = P.factor_bytes() + (P.fidx.size() + P.bidx.size()) * sizeof(int) + (size_t)2 * n * sizeof(NdRow);
     launches_ = 2 * P.nlevels - 1;
     factor_seconds = now_s() - t1;
     why = 0;
