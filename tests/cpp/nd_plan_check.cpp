@@ -3,7 +3,7 @@
 // emulation of what the device kernels of csrc/nd_kernels.hip do (scatter, extend-add by child slot, Gauss-Jordan
 // inverse of the pivot block with partial pivoting, the three products, forward pull, backward product) and the
 // result is checked against A x = b.  No GPU needed.
-//   argv: kind(grid2|grid3|box|rand|blocks) size leaf [merge_rows [top_merge_rows]]      (box: size = nx * 1000000 + ny * 1000 + nz)
+//   argv: kind(grid2|grid3|box|rand|blocks|arrow|diag) size leaf [merge_rows [top_merge_rows]]      (box: size = nx * 1000000 + ny * 1000 + nz)
 //   env ND_PLAN_ONLY=1: statistics of the plan only (large cases)
 #include <algorithm>
 #include <cmath>
@@ -96,7 +96,13 @@ int main(int argc, char **argv)
         std::mt19937 rng(12345);
         std::vector<std::vector<std::pair<int, double>>> rows((size_t)n);
         auto piece = [&](int i) { return kind == "blocks" ? (i == 0 ? 0 : (i < n / 3 ? 1 : 2)) : 0; };
+        if (kind == "arrow")  // tridiagonal + a full last row and column: diameter 2, no level structure to cut -> one dense block
+            for (int i = 0; i + 1 < n; ++i) {
+                rows[i].emplace_back(n - 1, -0.01);
+                rows[n - 1].emplace_back(i, -0.02);
+            }
         for (int i = 0; i < n; ++i) {
+            if (kind == "diag") break;  // only the diagonal: every row a component (and a leaf) of its own
             for (int q = 0; q < 3; ++q) {
                 const int span = 1 + (int)(rng() % 40);
                 int j = i + (int)(rng() % (2 * span + 1)) - span;

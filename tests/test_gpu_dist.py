@@ -442,8 +442,9 @@ def _tuned_run(rp, ci, v, b, G, delay_us, **kw):
     return out
 
 
-def test_measured_schedule_moves_with_the_transport_and_keeps_the_bits():
-    """the multi-rank schedule is chosen from measurements, not constants.  Two virtual ranks on one GPU, the
+@pytest.mark.parametrize("G", [2, 4])
+def test_measured_schedule_moves_with_the_transport_and_keeps_the_bits(G):
+    """the multi-rank schedule is chosen from measurements, not constants.  Two / four virtual ranks on one GPU, the
     in-process transport once as it is (a device copy: a few microseconds per call) and once with 400 us added to every call (a slow
     link).  The tuner must see the difference (measured exchange / all-reduce / all-gather times), replicate more levels over the
     slow link than over the fast one, never choose the exchange-per-sweep schedule on the slow link, hand every rank the same
@@ -455,7 +456,6 @@ def test_measured_schedule_moves_with_the_transport_and_keeps_the_bits():
     x1 = np.zeros(n)
     A1.vcycle(b, x1, iterations=3)
     A1.close()
-    G = 2
     fast = _tuned_run(rp, ci, v, b, G, 0.0)
     slow = _tuned_run(rp, ci, v, b, G, 400.0)
     for res in (fast, slow):
@@ -473,5 +473,5 @@ def test_measured_schedule_moves_with_the_transport_and_keeps_the_bits():
     for c in slow[0][2]:
         if c["partitioned"]:
             assert c["deep_halo"] and c["model_us_deep_halo"] < c["model_us_exchange_per_sweep"]
-    # over a 400 us link a 262 144-row problem is cheaper replicated than partitioned over two ranks (the whole V-cycle is ~1 ms)
+    # over a 400 us link a 262 144-row problem is cheaper replicated than partitioned (the whole V-cycle is ~1 ms)
     assert ns == 0, slow[0][2]

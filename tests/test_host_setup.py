@@ -235,6 +235,7 @@ def _nd_plan_check(tmp_path_factory, args, env=None):
 @pytest.mark.parametrize("args", [
     ("grid3", "10", "32"), ("grid3", "16", "64"), ("grid3", "12", "32", "0"), ("grid2", "40", "32"), ("grid2", "100", "64"),
     ("rand", "3000", "32"), ("blocks", "2000", "16"), ("grid3", "3", "64"), ("grid2", "7", "4"), ("box", "9006020", "16", "48"),
+    ("grid3", "16", "32", "96", "1024"), ("arrow", "300", "16"), ("diag", "200", "16"),
 ])
 def test_nested_dissection_plan_solves_on_the_host(tmp_path_factory, args):
     """csrc/nd_plan.cpp without a GPU: ordering, update sets, front positions, extend-add maps, forward segments and backward
@@ -297,4 +298,23 @@ def test_multi_rank_schedule_decision_follows_the_measured_transport():
     A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, print_solve=0), host_only=True)
     assert not any(c["partitioned"] for c in A.plan_comm_schedule(8, **link(15.0), **dev))
     assert sum(c["partitioned"] for c in A.plan_comm_schedule(8, **link(0.0), **dev)) >= 3
+    A.close()
+
+
+def test_refused_coarsest_level_extends_the_hierarchy_host_side():
+    """ADVICE r2 (host half; the device half is tests/test_gpu_coarse.py::test_refused_coarsest_level_extends_the_hierarchy): with the
+    default parameters a 200 000-row random sparsity pattern leaves 6 250 rows after 6 levels... below dense_limit, so force the issue
+    with dense_limit = 2000: the direct solver's plan refuses a graph without separators (factors would exceed a quarter of the dense
+    inverse), and the setup answers by extending the hierarchy with the reference's own coarsening rule instead of failing."""
+    rp, ci, v = problems.random_spd(400000, 9, seed=5)
+    for form in ("nd", "bt"):
+        A = sa.sp_matrix_mg(rp, ci, v).set_coarse_form(form).setup(sa.default_params(print_setup=0, print_solve=0, dense_limit=4000), host_only=True)
+        info = A.coarse_info()
+        assert A.nlevels > 6 and info["dense"] and info["extended"] and info["rows"] <= 4000, (form, A.nlevels, info)
+        A.close()
+    # a graph WITH separators of the same size is accepted as it is: 6 levels, no dense inverse
+    rp, ci, v = problems.poisson2d(632)   # 399 424 rows -> 12 482 after 5 halvings
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, print_solve=0, dense_limit=4000), host_only=True)
+    info = A.coarse_info()
+    assert A.nlevels == 6 and not info["dense"] and not info["extended"] and info["rows"] > 4000
     A.close()
