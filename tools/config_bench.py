@@ -103,6 +103,15 @@ def main():
         res["C2D_poisson2d_1000_beck"] = run("C2D Beck", *problems.poisson2d(1000), ["amg", "pcg"], coarsening=1)
     if want("C3D_poisson3d_216_beck"):
         res["C3D_poisson3d_216_beck"] = run("C3D 216^3 Beck", *problems.poisson3d(216), ["amg", "pcg"], coarsening=1)
+    # larger inputs (only when asked for by name): robustness of the nested-dissection solver on big 2D / unstructured coarsest levels
+    if only and want("BIG_poisson2d_3000_reference_policy"):   # 9 M rows, the reference's 6 levels: 281 250-row 2D coarsest level to the direct solver
+        res["BIG_poisson2d_3000_reference_policy"] = run("2D 3000^2 ref", *problems.poisson2d(3000), ["amg", "pcg"], coarse_limit=1 << 30)
+    if only and want("BIG_poisson2d_3000_default"):
+        res["BIG_poisson2d_3000_default"] = run("2D 3000^2", *problems.poisson2d(3000), ["amg", "pcg"])
+    if only and want("BIG_fem_unstructured_2M"):
+        res["BIG_fem_unstructured_2M"] = run("FEM 2M", *problems.fem_unstructured(2000000, seed=3), ["pcg"], rhs="random")
+    if only and want("BIG_fem_unstructured_2M_reference_policy"):
+        res["BIG_fem_unstructured_2M_reference_policy"] = run("FEM 2M ref", *problems.fem_unstructured(2000000, seed=3), ["pcg"], rhs="random", coarse_limit=1 << 30)
     mtx = os.environ.get("SPARSH_MTX")  # e.g. SuiteSparse parabolic_fem.mtx when it is on the box
     if mtx and os.path.exists(mtx):
         if want("CU_"):
