@@ -84,6 +84,12 @@ typedef struct sparsh_params {
                            a direct solve" that fits; > 0 = at the first level of at most that many rows
                            (4000 = limit_upper: round 2's behaviour, 13 levels at 10 M rows).
                                                                                [SPARSH_EXTEND_UNTIL] */
+    int coarse_factor_mb; /* the reference's own coarsest level (what max_levels leaves) is kept, whatever its row count, while the
+                           ESTIMATED size of its nested-dissection factors stays below this many MB (one breadth-first search gives
+                           the graph's effective dimension: ~ n log n bytes for 2D-like operators, ~ n^(4/3) for 3D-like ones).
+                           Default 1024: a 9 M-row 2D problem keeps the reference's 6 levels (281 250-row direct solve, 0.5 GB),
+                           136^3 does (78 608 rows, 0.4 GB), 216^3 does not (314 928 rows, 2.4 GB: extended).  0: coarse_limit
+                           alone decides.                                      [SPARSH_COARSE_FACTOR_MB] */
 } sparsh_params;
 
 typedef struct sparsh_handle_s *sparsh_handle;

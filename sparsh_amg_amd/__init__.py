@@ -59,6 +59,7 @@ class Params(C.Structure):
         ("precond_fp32", C.c_int),
         ("dense_limit", C.c_int),
         ("extend_until", C.c_int),
+        ("coarse_factor_mb", C.c_int),
     ]
 
 

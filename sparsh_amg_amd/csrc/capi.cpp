@@ -116,6 +116,7 @@ void sparsh_default_params(sparsh_params *p)
     p->coarse_limit = env_int("SPARSH_COARSE_LIMIT", 40000);
     p->dense_limit = env_int("SPARSH_DENSE_LIMIT", 8192);
     p->extend_until = env_int("SPARSH_EXTEND_UNTIL", 0);
+    p->coarse_factor_mb = env_int("SPARSH_COARSE_FACTOR_MB", 1024);
     p->host_threads = env_int("SPARSH_THREADS", 0);
     p->device = -1;
     if (const char *lr = std::getenv("LOCAL_RANK")) p->device = std::atoi(lr);

@@ -477,6 +477,8 @@ int Engine::setup_host(const sparsh_params &p)
     sp.coarse_limit = p.coarse_limit;
     if (p.dense_limit > 0) sp.dense_limit = p.dense_limit;
     sp.extend_until = p.extend_until;
+    sp.coarse_factor_bytes = p.coarse_factor_mb > 0 ? (size_t)p.coarse_factor_mb << 20 : 0;
+    if (coarse_.form() == 1) sp.coarse_factor_bytes = 0;  // the estimate is the nested-dissection solver's
     sp.host_threads = p.host_threads;
     sp.print = p.print_setup != 0;
     if (!build_hierarchy(A0_, sp, H_)) {
@@ -495,6 +497,7 @@ int Engine::setup_host(const sparsh_params &p)
             SetupParams sp2 = sp;
             sp2.coarse_limit = sp.dense_limit;
             sp2.extend_until = sp.limit_upper;
+            sp2.coarse_factor_bytes = 0;
             const double before = H_.seconds;
             if (!build_hierarchy(A0_, sp2, H_)) {
                 error = H_.error;

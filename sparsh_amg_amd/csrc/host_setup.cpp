@@ -562,7 +562,14 @@ bool build_hierarchy(const HostCsr &A0, const SetupParams &prm, HostHierarchy &H
         // above).  Opt-out for very large problems: if max_levels would leave more than coarse_limit
         // rows, keep coarsening by the same rule until the direct solver can take over (n <= coarse_limit;
         // extend_until > 0: until n <= extend_until, e.g. limit_upper as in round 2).
-        if (!within_ref && n > prm.coarse_limit) H.extended = true;
+        // ... unless the direct solver can afford the reference's own coarsest level anyway: nested-dissection factors of a 2D-like
+        // operator grow like n log n, so 281 250 rows of a 9 M-row 2D problem cost less than 39 366 rows of a 3D one.
+        if (!within_ref && !H.extended && n > prm.coarse_limit) {
+            const bool affordable = l == prm.max_levels - 1 && prm.coarse_factor_bytes > 0 && n > prm.dense_limit &&
+                                    nd_estimate_factor_bytes(H.levels[l].A) <= prm.coarse_factor_bytes;
+            if (affordable) break;
+            H.extended = true;
+        }
         const int stop_at = within_ref ? prm.limit_upper : std::max(prm.limit_upper, prm.extend_until > 0 ? prm.extend_until : prm.coarse_limit);
         if (!(n > stop_at && (within_ref || H.extended))) break;
         if (prm.print) std::printf("Level %d:\t%d\n", l, n);

@@ -55,6 +55,8 @@ struct SetupParams {
     int coarse_limit = 40000;  // largest coarsest level max_levels may leave (above: keep coarsening)
     int dense_limit = 8192;    // largest coarsest level solved with an explicit dense inverse
     int extend_until = 0;      // an extended hierarchy stops at the first level of at most this many rows (0: coarse_limit)
+    size_t coarse_factor_bytes = (size_t)1 << 30;  // the reference's own coarsest level is kept, whatever its rows, while its estimated
+                                                   // nested-dissection factors stay below this (0: coarse_limit alone decides)
     int host_threads = 0;
     bool print = true;
 };
@@ -91,6 +93,9 @@ std::vector<double> extract_diagonal(const HostCsr &A);
 std::vector<int> rcm_order(const HostCsr &A);
 // dense inverse of a sparse matrix through RCM + banded LU (partial pivoting); false if singular
 bool sparse_inverse(const HostCsr &A, std::vector<double> &inv);
+
+// rough size of the nested-dissection factors of A (nd_plan.cpp; one breadth-first search, no dissection)
+size_t nd_estimate_factor_bytes(const HostCsr &A);
 
 // whole setup
 bool build_hierarchy(const HostCsr &A0, const SetupParams &prm, HostHierarchy &H);

@@ -2,6 +2,7 @@
 // available on the pool).  One translation unit: host_setup.cpp + dist.cpp.
 #include "../../sparsh_amg_amd/csrc/host_setup.cpp"
 #include "../../sparsh_amg_amd/csrc/dist.cpp"
+#include "../../sparsh_amg_amd/csrc/nd_plan.cpp"
 
 #include <cstdio>
 #include <cstdlib>
@@ -96,6 +97,44 @@ int main()
                     }
             }
         }
+    }
+    {   // nested-dissection plan of a coarse operator (ordering, symbolic factorisation, solve schedule) under the sanitizers
+        HostHierarchy H;
+        SetupParams sp;
+        sp.print = false;
+        sp.max_levels = 3;
+        sp.dense_limit = 100;
+        const int m = 40;
+        std::vector<int> rp(1, 0), ci;
+        std::vector<double> v;
+        for (int y = 0; y < m; ++y)
+            for (int x = 0; x < m; ++x) {
+                const int i = y * m + x;
+                if (y > 0) ci.push_back(i - m), v.push_back(-1.0);
+                if (x > 0) ci.push_back(i - 1), v.push_back(-1.0);
+                ci.push_back(i), v.push_back(4.0);
+                if (x < m - 1) ci.push_back(i + 1), v.push_back(-1.0);
+                if (y < m - 1) ci.push_back(i + m), v.push_back(-1.0);
+                rp.push_back((int)ci.size());
+            }
+        const HostCsr A = HostCsr::alias(m * m, m * m, rp.data(), ci.data(), v.data());
+        if (!build_hierarchy(A, sp, H)) return 4;
+        for (int leaf : {4, 16, 64}) {
+            NdParams np;
+            np.leaf = leaf;
+            np.merge_rows = leaf == 4 ? 0 : 48;
+            np.top_merge_rows = leaf == 64 ? 128 : 0;
+            NdPlan P;
+            std::string err;
+            if (!nd_make_plan(H.levels.back().A, np, P, err)) {
+                std::printf("nd plan failed: %s\n", err.c_str());
+                return 5;
+            }
+            size_t rows = 0;
+            for (const NdPass &ps : P.bwd) rows += ps.rows.size();
+            if ((int)rows != P.n || P.fidx.size() != P.l_doubles) return 6;
+        }
+        if (nd_estimate_factor_bytes(A) == 0) return 7;
     }
     std::printf("ASAN_HOST_OK\n");
     return 0;

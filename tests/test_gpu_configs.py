@@ -266,33 +266,40 @@ def test_config2_full_size_properties():
     assert abs(z1 @ b2 - z2 @ b1) <= 1e-10 * abs(z1 @ b2)
 
 
-def test_extended_hierarchy_stop_policy():
-    """Where a hierarchy that must be extended past level1 = 6 stops (sparsh_params.extend_until): by default at the first level the
-    device direct solver takes (<= coarse_limit rows), with extend_until = limit_upper at <= 4000 rows as in round 2.  Both are the
-    reference's coarsening rule applied further (same operators level by level), both converge to the same solution."""
+def test_level_policy_beyond_coarse_limit():
+    """What happens when level1 = 6 levels leave more than coarse_limit rows (sparsh_params.coarse_factor_mb / extend_until): 130^3
+    leaves 68 657 rows.  Default: the reference's own coarsest level is KEPT, because its nested-dissection factors are estimated
+    affordable (n^(4/3) growth, ~0.3 GB < 1 GB) -- the hierarchy is exactly the reference's.  coarse_factor_mb = 0: the row rule alone
+    decides and the hierarchy is extended by the same coarsening rule to the first level of <= coarse_limit rows; with extend_until = 4000
+    on to <= 4000 rows as in round 2.  All three are the reference's coarsening applied to the same operators, and all three converge
+    to the same solution."""
     import scipy.sparse as sp
 
-    rp, ci, v = problems.poisson3d(130)   # 2 197 000 rows: 6 levels would leave 68 657 rows
+    rp, ci, v = problems.poisson3d(130)   # 2 197 000 rows
     n = len(rp) - 1
     S = sp.csr_matrix((v, ci, rp), shape=(n, n))
     b = np.ones(n)
-    xs, lv = [], []
-    for eu in (0, 4000):
-        A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET, extend_until=eu))
+    xs, lv, its = [], [], []
+    for kw in (dict(), dict(coarse_factor_mb=0), dict(coarse_factor_mb=0, extend_until=4000)):
+        A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET, **kw))
         levels = [A.level_info(l)["nrow"] for l in range(A.nlevels)]
         info = A.coarse_info()
-        assert info["extended"] and levels[5] > 40000
-        if eu == 0:
-            assert A.nlevels == 7 and 20000 < levels[-1] <= 40000 and info["form"] == "nested_dissection"
+        if not kw:
+            assert A.nlevels == 6 and levels[-1] == 68657 and not info["extended"] and info["form"] == "nested_dissection"
+            assert info["bytes"] < 1 << 30   # the estimate that admitted the level was not optimistic
+        elif "extend_until" not in kw:
+            assert A.nlevels == 7 and 20000 < levels[-1] <= 40000 and info["extended"] and info["form"] == "nested_dissection" and levels[:6] == lv[0]
         else:
-            assert levels[-1] <= 4000 and info["dense"] and levels[:7] == lv[0]
+            assert levels[-1] <= 4000 and info["dense"] and info["extended"] and levels[:7] == lv[1]
         x = np.zeros(n)
         h, rc = A.solve("pcg", b, x)
         assert rc == 0 and np.linalg.norm(b - S @ x) <= 5e-8
         xs.append(x)
         lv.append(levels)
+        its.append(len(h))
         A.close()
-    assert np.linalg.norm(xs[0] - xs[1]) <= 1e-7 * np.linalg.norm(xs[0])
+    assert np.linalg.norm(xs[0] - xs[1]) <= 1e-7 * np.linalg.norm(xs[0]) and np.linalg.norm(xs[0] - xs[2]) <= 1e-7 * np.linalg.norm(xs[0])
+    assert its[0] <= its[1] <= its[2]   # a shallower hierarchy with an exact coarsest solve needs no more iterations
 
 
 @pytest.mark.parametrize("form", ["nd", "bt"])

@@ -108,11 +108,20 @@ def test_coarse_inverse_needs_pivoting():
 
 
 def test_extended_hierarchy():
-    # max_levels too small for coarse_limit: hierarchy is extended (documented deviation)
+    # max_levels too small for coarse_limit (rows alone deciding): hierarchy is extended (documented deviation)
     rp, ci, v = problems.poisson2d(200)
-    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, max_levels=2, coarse_limit=5000), host_only=True)
-    assert A.nlevels > 2
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, max_levels=2, coarse_limit=5000, coarse_factor_mb=0), host_only=True)
+    assert A.nlevels > 2 and A.coarse_info()["extended"]
     assert A.level_info(A.nlevels - 1)["nrow"] <= 5000
+    A.close()
+    # default: the reference's own coarsest level stays when its nested-dissection factors are estimated affordable (20 000 rows of a 2D operator)
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, max_levels=2, coarse_limit=5000), host_only=True)
+    assert A.nlevels == 2 and not A.coarse_info()["extended"]
+    A.close()
+    # ... and is given up when they are not: the same with a 1 MB budget
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, max_levels=2, coarse_limit=5000, coarse_factor_mb=1), host_only=True)
+    assert A.nlevels > 2 and A.coarse_info()["extended"]
+    A.close()
 
 
 def test_index16_encoder_roundtrip():

@@ -82,8 +82,10 @@ def main():
     # 78 608-row coarsest level; next to it the default (hierarchy extended until <= 40 000 rows)
     if want("C3D_poisson3d_136_reference_policy"):
         res["C3D_poisson3d_136_reference_policy"] = run("136^3 ref", *problems.poisson3d(136), ["amg", "pcg"], coarse_limit=100000)
-    if want("C3D_poisson3d_136_default"):
+    if want("C3D_poisson3d_136_default"):   # since the factor-size rule (coarse_factor_mb): the reference's 6 levels
         res["C3D_poisson3d_136_default"] = run("136^3", *problems.poisson3d(136), ["amg", "pcg"])
+    if want("C3D_poisson3d_136_row_rule"):  # coarse_limit rows alone: extended to 39 304 rows
+        res["C3D_poisson3d_136_row_rule"] = run("136^3 rows", *problems.poisson3d(136), ["amg", "pcg"], coarse_factor_mb=0)
     if want("C3D_poisson3d_216"):
         res["C3D_poisson3d_216"] = run("C3D", *problems.poisson3d(216), ["amg", "pcg"])
     if want("C3D_poisson3d_216_round2_hierarchy"):  # extended until <= limit_upper rows: 13 levels, dense 2468-row coarsest level
@@ -105,9 +107,11 @@ def main():
         res["C3D_poisson3d_216_beck"] = run("C3D 216^3 Beck", *problems.poisson3d(216), ["amg", "pcg"], coarsening=1)
     # larger inputs (only when asked for by name): robustness of the nested-dissection solver on big 2D / unstructured coarsest levels
     if only and want("BIG_poisson2d_3000_reference_policy"):   # 9 M rows, the reference's 6 levels: 281 250-row 2D coarsest level to the direct solver
-        res["BIG_poisson2d_3000_reference_policy"] = run("2D 3000^2 ref", *problems.poisson2d(3000), ["amg", "pcg"], coarse_limit=1 << 30)
-    if only and want("BIG_poisson2d_3000_default"):
-        res["BIG_poisson2d_3000_default"] = run("2D 3000^2", *problems.poisson2d(3000), ["amg", "pcg"])
+        res["BIG_poisson2d_3000_reference_policy"] = run("2D 3000^2 ref", *problems.poisson2d(3000), ["pcg"], coarse_limit=1 << 30)
+    if only and want("BIG_poisson2d_3000_default"):   # (= the reference policy since the factor-size rule)
+        res["BIG_poisson2d_3000_default"] = run("2D 3000^2", *problems.poisson2d(3000), ["pcg"])
+    if only and want("BIG_poisson2d_3000_row_rule"):
+        res["BIG_poisson2d_3000_row_rule"] = run("2D 3000^2 rows", *problems.poisson2d(3000), ["pcg"], coarse_factor_mb=0)
     if only and want("BIG_fem_unstructured_2M"):
         res["BIG_fem_unstructured_2M"] = run("FEM 2M", *problems.fem_unstructured(2000000, seed=3), ["pcg"], rhs="random")
     if only and want("BIG_fem_unstructured_2M_reference_policy"):
