@@ -393,6 +393,30 @@ def test_graph_replay_matches_eager():
     assert np.array_equal(hs, h0[:7])
 
 
+def test_graph_replay_with_device_factored_coarsest_level():
+    """use_graph with a coarsest level above dense_limit: the nested-dissection solve (2 * tree levels - 1 launches, no host
+    synchronisation) is captured with the rest of the iteration -- same launches, same buffers, same bits; and changing a kernel
+    setting afterwards drops the captured graph instead of replaying stale launches."""
+    rp, ci, v = problems.poisson3d(64)   # 262 144 rows -> 6 levels, 8192-row coarsest level
+    b = np.ones(len(rp) - 1)
+    res = []
+    for graph in (0, 1):
+        A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET, dense_limit=4000, use_graph=graph))
+        assert A.coarse_info()["form"] == "nested_dissection"
+        x = np.zeros_like(b)
+        h, rc = A.solve("pcg", b, x)
+        assert rc == 0
+        res.append((h, x))
+        if graph:
+            A.set_kernel_config(0, 3, -1, -1)   # CSR-stream family from now on: the graph of the table-path launches must not be replayed
+            x2 = np.zeros_like(b)
+            h2, rc2 = A.solve("pcg", b, x2)
+            assert rc2 == 0 and A.level_kernel(0).startswith("csr_")
+            assert np.array_equal(h2, h) and np.array_equal(x2, x)   # every family is bitwise equal: only a stale replay could differ (or crash)
+        A.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
 def _mixed_coefficients(n):
     """5-pt stencil with a variable diagonal and a partly variable east coupling: slices hold constant
     and non-constant diagonals side by side."""
