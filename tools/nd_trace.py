@@ -56,13 +56,35 @@ def summarize(d):
     print(f"# first start -> last end: {(prev_end - t0) / 1e3:.2f} us; sum of kernel durations {tot:.2f} us")
 
 
+def summarize_pmc(fetch_dir, write_dir):
+    """HBM bytes of one coarse solve from two counter passes of --run (FETCH_SIZE, WRITE_SIZE): sum over the nd_gdot_kernel dispatches of the
+    last 20 solves.  FETCH_SIZE x 1.9997 (8-byte per-lane loads on gfx950: calibrated in tools/pmc_traffic.py), WRITE_SIZE exact; KiB -> bytes."""
+    info = json.load(open("/tmp/nd_trace_info.json")) if os.path.exists("/tmp/nd_trace_info.json") else {}
+    per = info.get("nd_launches_per_solve") or 1
+    out = {}
+    for name, d, corr in (("read", fetch_dir, 1.9997), ("write", write_dir, 1.0)):
+        f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+        rows = [r for r in csv.DictReader(open(f)) if "nd_gdot_kernel" in r["Kernel_Name"]]
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        last = rows[-20 * per:]
+        out[name] = sum(float(r["Counter_Value"]) for r in last) * 1024.0 * corr / 20.0
+    total = out["read"] + out["write"]
+    print(json.dumps({"coarsest_level": info, "hbm_read_bytes_per_solve": out["read"], "hbm_write_bytes_per_solve": out["write"],
+                      "hbm_bytes_per_solve": total, "factor_and_index_bytes": info.get("bytes"),
+                      "traffic_over_bytes": total / info["bytes"] if info.get("bytes") else None,
+                      "GBps_at_back_to_back_rate": total / (info["coarse_solve_us_hip_events"] * 1e-6) / 1e9 if info.get("coarse_solve_us_hip_events") else None}, indent=1))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--run", action="store_true")
     ap.add_argument("--case", default="100")
     ap.add_argument("--summarize")
+    ap.add_argument("--summarize-pmc", nargs=2, metavar=("FETCH_DIR", "WRITE_DIR"))
     a = ap.parse_args()
     if a.run:
         run(a.case)
+    elif a.summarize_pmc:
+        summarize_pmc(*a.summarize_pmc)
     else:
         summarize(a.summarize)
