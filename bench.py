@@ -137,8 +137,6 @@ def main():
             H.set_index_compression(idx16)
         if cfg:
             H.set_kernel_config(*cfg)
-        if os.environ.get("SPARSH_COARSE_PREFETCH"):  # A/B of the coarse-factor prefetch
-            H.set_coarse_prefetch(os.environ["SPARSH_COARSE_PREFETCH"] != "0")
         return H
 
     if sa.device_count() < 1:

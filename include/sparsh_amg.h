@@ -244,10 +244,6 @@ int sparsh_set_coarse_form(sparsh_handle h, int form, int leaf, int merge_rows);
  * meets merge_rows (default 2048; 0 = merge_rows everywhere).  Near the root a tree level holds 1, 2, 4 ... nodes and costs two
  * dependent launches per solve whatever it holds. */
 int sparsh_set_coarse_top_merge(sparsh_handle h, int top_merge_rows);
-/* While a V-cycle descends through its last three (launch-bound) levels a side stream reads the nested-dissection factors, so that the
- * direct solve finds them in the 256 MB Infinity Cache instead of HBM; a hint, not a dependency (the solve never waits for it).
- * Default on; 0 switches it off (A/B measurements).  Never active inside a hipGraph capture. */
-int sparsh_set_coarse_prefetch(sparsh_handle h, int enable);
 int sparsh_coarse_nd_info(sparsh_handle h, int *info6);
 /* Interface form of the block-tridiagonal solve: where the RCM band is narrow against the block (2 * window <= block,
  * window = bandwidth rounded up to 64) only the first / last `window` rows of a block couple to its neighbours, so the

@@ -114,7 +114,6 @@ def _load():
         "sparsh_set_coarse_form": (C.c_int, [H, C.c_int, C.c_int, C.c_int]),
         "sparsh_coarse_nd_info": (C.c_int, [H, c_int_p]),
         "sparsh_set_coarse_top_merge": (C.c_int, [H, C.c_int]),
-        "sparsh_set_coarse_prefetch": (C.c_int, [H, C.c_int]),
         "sparsh_setup_seconds": (C.c_double, [H]),
         "sparsh_vcycle": (C.c_int, [H, c_dbl_p, c_dbl_p, C.c_int, c_dbl_p, C.c_int, c_int_p]),
         "sparsh_vcycle_dev": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int, c_dbl_p, C.c_int, c_int_p]),
@@ -459,11 +458,6 @@ class sp_matrix_mg:
     def set_coarse_interface(self, enable=True):
         """Interface (window) form of the block-tridiagonal coarse solve, default on; call before setup."""
         _check(lib.sparsh_set_coarse_interface(self._h, int(enable)))
-        return self
-
-    def set_coarse_prefetch(self, enable=True):
-        """Side-stream prefetch of the nested-dissection factors into the Infinity Cache ahead of the coarsest solve (default on)."""
-        _check(lib.sparsh_set_coarse_prefetch(self._h, int(bool(enable))))
         return self
 
     def set_comm_tuning(self, enable=True):

@@ -505,13 +505,6 @@ int sparsh_set_coarse_form(sparsh_handle h, int form, int leaf, int merge_rows)
     return SPARSH_OK;
 }
 
-int sparsh_set_coarse_prefetch(sparsh_handle h, int enable)
-{
-    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
-    h->eng->set_coarse_prefetch(enable != 0);
-    return SPARSH_OK;
-}
-
 int sparsh_set_coarse_top_merge(sparsh_handle h, int top_merge_rows)
 {
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");

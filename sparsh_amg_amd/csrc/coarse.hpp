@@ -72,11 +72,6 @@ public:
     bool setup_nd(const HostCsr &A, hipStream_t st, std::string &err, int *why_failed = nullptr);
     // x = A^-1 b, device vectors in the operator's own numbering; enqueues on st
     void solve(const double *b, double *x, hipStream_t st) const;
-    // nested-dissection form: touch the factors on a side stream so that the next solve finds them in the Infinity Cache
-    void prefetch(hipStream_t st) const
-    {
-        if (nd_.ready()) nd_.prefetch(st);
-    }
     void release();
 
     bool ready() const { return n_ > 0; }

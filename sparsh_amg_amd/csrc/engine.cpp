@@ -87,8 +87,6 @@ Engine::~Engine()
     if (ev_ready_) (void)hipEventDestroy(ev_ready_);
     if (ev_halo_) (void)hipEventDestroy(ev_halo_);
     if (st2_) (void)hipStreamDestroy(st2_);
-    if (pf_ev_) (void)hipEventDestroy(pf_ev_);
-    if (pf_st_) (void)hipStreamDestroy(pf_st_);
     if (st_) (void)hipStreamDestroy(st_);
 }
 
@@ -1620,21 +1618,8 @@ void Engine::vcycle(const double *b0, bool x0_zero, double *dot_partial, int *do
         return;
     }
     bool zero_done = zero_done0 && x0_zero;  // the previous level's restriction (level 0: the caller) already wrote this level's zero-guess sweep
-    // three smoothing legs ahead of the direct solve (launch-bound levels: HBM idle) start pulling its factors into the Infinity Cache
-    const int pf_level = (coarse_prefetch_ && coarse_.nested() && !capturing_ && last >= 2) ? std::max(0, last - 3) : -1;
     for (int l = 0; l < last; ++l) {
         DevLevel &L = lev_[l];
-        if (l == pf_level) {
-            if (!pf_st_) {
-                HIPCHK(hipStreamCreateWithFlags(&pf_st_, hipStreamNonBlocking));
-                HIPCHK(hipEventCreateWithFlags(&pf_ev_, hipEventDisableTiming));
-            }
-            if (pf_st_ && pf_ev_) {
-                HIPCHK(hipEventRecord(pf_ev_, st_));
-                HIPCHK(hipStreamWaitEvent(pf_st_, pf_ev_, 0));
-                coarse_.prefetch(pf_st_);
-            }
-        }
         if (L.deep) {
             // deep-halo leg: one exchange of the right-hand side's ghost layers (and of the iterate's, unless it
             // is zero) replaces the exchange in front of every sweep and of the residual
@@ -1804,9 +1789,7 @@ bool Engine::capture_graph(bool precond)
 {
     drop_graph();
     if (hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
-    capturing_ = true;  // (no side-stream work inside a capture)
     pcg_body(precond, -1);
-    capturing_ = false;
     hipGraph_t g = nullptr;
     if (hipStreamEndCapture(st_, &g) != hipSuccess || !g) return false;
     hipGraphExec_t e = nullptr;

@@ -119,7 +119,6 @@ public:
     // device's sweep rate, then choose from those numbers which levels are partitioned and whether the partitioned levels smooth
     // with deep halos or exchange per sweep (mode 1, default).  Mode 0: replicate_rows / set_deep_halo decide, as in round 2.
     void set_comm_tuning(int mode) { comm_tune_ = mode; }
-    void set_coarse_prefetch(int on) { coarse_prefetch_ = on; }
     struct CommLevelChoice {
         int rows = 0, halo_rows = 0;
         bool partitioned = false, deep = false;
@@ -250,12 +249,6 @@ private:
     void decide_comm_schedule(const sparsh_params &p, int G);
     long n_exchanges_ = 0;          // transport calls issued (halo / staged exchanges; diagnostics)
     hipStream_t st2_ = nullptr;     // exchange stream of the overlap path
-    // coarse-factor prefetch: while the V-cycle descends through its launch-bound levels (HBM idle) a side stream pulls the
-    // nested-dissection factors into the Infinity Cache; the solve itself does not wait for it (a hint, not a dependency)
-    hipStream_t pf_st_ = nullptr;
-    hipEvent_t pf_ev_ = nullptr;
-    int coarse_prefetch_ = 1;       // 0 off
-    bool capturing_ = false;
     hipEvent_t ev_ready_ = nullptr, ev_halo_ = nullptr;
     std::vector<F32Level> f32_;
     float *coarse_inv_f32_ = nullptr;

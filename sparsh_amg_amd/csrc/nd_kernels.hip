@@ -404,28 +404,7 @@ __global__ __launch_bounds__(kNB) void nd_gdot_kernel(const NdRow *__restrict__ 
     }
 }
 
-// touches a range of the factors (default cache policy: the lines land in the Infinity Cache) -- launched on a side stream while the
-// launch-bound coarse levels of a V-cycle leave HBM idle, so that the solve that follows reads its factors from the cache
-__global__ __launch_bounds__(kNB) void nd_prefetch_kernel(const double2 *__restrict__ p, size_t n16, double *__restrict__ sink)
-{
-    double acc = 0.0;
-    for (size_t i = (size_t)blockIdx.x * kNB + threadIdx.x; i < n16; i += (size_t)gridDim.x * kNB) {
-        const double2 v = p[i];
-        acc += v.x + v.y;
-    }
-    if (acc == 1.2345678e300) *sink = acc;  // never true: keeps the loads
-}
-
 }  // namespace
-
-void nd_launch_prefetch(const void *p, size_t bytes, double *sink, hipStream_t st)
-{
-    const size_t n16 = bytes / 16;
-    if (n16 == 0) return;
-    size_t g = (n16 + kNB * 8 - 1) / (kNB * 8);
-    if (g > 512) g = 512;  // a fraction of the chip: it shares it with the V-cycle's own launches
-    hipLaunchKernelGGL(nd_prefetch_kernel, dim3((unsigned)g), dim3(kNB), 0, st, static_cast<const double2 *>(p), n16, sink);
-}
 
 void nd_launch_scatter(long long cnt, const long long *dst, const double *val, double *fronts, hipStream_t st)
 {

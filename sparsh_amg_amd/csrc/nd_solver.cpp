@@ -289,20 +289,9 @@ bool NdSolver::setup(const HostCsr &A, const NdParams &prm, hipStream_t st, std:
     // backward pass) and the row records
     factor_bytes_ = P.factor_bytes() + (P.fidx.size() + P.bidx.size()) * sizeof(int) + (size_t)2 * n * sizeof(NdRow);
     launches_ = 2 * P.nlevels - 1;
-    b_bytes_ = P.b_doubles * sizeof(double);
-    l_bytes_ = P.l_doubles * sizeof(double);
-    fidx_bytes_ = P.fidx.size() * sizeof(int);
     factor_seconds = now_s() - t1;
     why = 0;
     return true;
-}
-
-void NdSolver::prefetch(hipStream_t st) const
-{
-    if (n_ <= 0) return;
-    nd_launch_prefetch(Lf_, l_bytes_, w_, st);
-    nd_launch_prefetch(fidx_, fidx_bytes_, w_, st);
-    nd_launch_prefetch(Bm_, b_bytes_, w_, st);
 }
 
 void NdSolver::solve(const double *b, double *x, hipStream_t st) const

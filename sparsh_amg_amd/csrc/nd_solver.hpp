@@ -46,7 +46,6 @@ public:
     // why_failed: 1 the plan was refused (graph / memory limits), 2 singular, 3 device error
     bool setup(const HostCsr &A, const NdParams &prm, hipStream_t st, std::string &err, int *why_failed);
     void solve(const double *b, double *x, hipStream_t st) const;  // device vectors, the operator's own numbering
-    void prefetch(hipStream_t st) const;                           // pull the factors into the Infinity Cache (side stream)
     void release();
 
     bool ready() const { return n_ > 0; }
@@ -72,7 +71,6 @@ private:
         int nrows = 0, nwide = 0;
     };
     std::vector<Pass> fwd_, bwd_;  // per tree level
-    size_t b_bytes_ = 0, l_bytes_ = 0, fidx_bytes_ = 0;
 };
 
 // launchers of nd_kernels.hip
@@ -81,7 +79,6 @@ void nd_launch_extend_add(const NdDevNode *nodes, const int *children, int nchil
 void nd_launch_invert(const NdDevNode *nodes, const int *list, int count, const double *fronts, double *Bm, int *singular, hipStream_t st);
 void nd_launch_gj_batched(const NdGjNode *nodes, int nnodes, const int *wg_node, int nwg, int max_p, int *singular, hipStream_t st);
 void nd_launch_gemm(const NdGemm *problems, const int *tiles, int ntiles, hipStream_t st);
-void nd_launch_prefetch(const void *p, size_t bytes, double *sink, hipStream_t st);
 void nd_launch_repack(long long nseg, const NdSegment *segs, const double *Lh, double *Lf, hipStream_t st);
 void nd_launch_pass(bool forward, const NdRow *rows, int nrows, int nwide, int n, const double *M, const int *idx, double *w, const double *b, double *x,
                     hipStream_t st);

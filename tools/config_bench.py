@@ -28,8 +28,6 @@ def run(name, rp, ci, v, methods, rhs="ones", **params):
     if os.environ.get("SPARSH_COARSE_FORM"):   # "nd[,leaf[,merge_rows]]" or "bt": A/B of the two device factorisations
         f = os.environ["SPARSH_COARSE_FORM"].split(",")
         A.set_coarse_form(f[0], int(f[1]) if len(f) > 1 else 0, int(f[2]) if len(f) > 2 else -1, int(f[3]) if len(f) > 3 else -1)
-    if os.environ.get("SPARSH_COARSE_PREFETCH"):
-        A.set_coarse_prefetch(os.environ["SPARSH_COARSE_PREFETCH"] != "0")
     A.setup(sa.default_params(print_setup=0, print_solve=0, **params))
     out["levels"] = [A.level_info(l)["nrow"] for l in range(A.nlevels)]
     out["level_kernels"] = [A.level_kernel(l) for l in range(A.nlevels - 1)]
