@@ -841,10 +841,20 @@ bool Engine::measure_transport()
         for (double *q : {vec, ag, ax, slots})
             if (q) (void)hipFree(q);
     };
-    if (hipMalloc(reinterpret_cast<void **>(&vec), (size_t)4 * large * 8) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&ag), (size_t)agn_large * 8) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&ax), (size_t)2 * axn_large * 8) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&slots), (size_t)G * 8 * 8) != hipSuccess) {
-        cleanup();
-        return false;
+    // the small table first: with it every rank can tell the others whether its larger buffers could be allocated, so that either
+    // all ranks go on to the timed collectives or none does (a rank that left alone would leave the others waiting in an exchange)
+    if (hipMalloc(reinterpret_cast<void **>(&slots), (size_t)G * 8 * 8) != hipSuccess) return false;
+    {
+        const bool mine = hipMalloc(reinterpret_cast<void **>(&vec), (size_t)4 * large * 8) == hipSuccess &&
+                          hipMalloc(reinterpret_cast<void **>(&ag), (size_t)agn_large * 8) == hipSuccess &&
+                          hipMalloc(reinterpret_cast<void **>(&ax), (size_t)2 * axn_large * 8) == hipSuccess;
+        double f = mine ? 0.0 : 1.0;
+        const bool okf = check(hipMemcpyAsync(slots, &f, sizeof(double), hipMemcpyHostToDevice, st_), "hipMemcpy") && comm_->allreduce_sum(slots, 1, st_) &&
+                         check(hipMemcpyAsync(&f, slots, sizeof(double), hipMemcpyDeviceToHost, st_), "hipMemcpy") && check(hipStreamSynchronize(st_), "hipStreamSynchronize");
+        if (!okf || f != 0.0) {
+            cleanup();
+            return false;
+        }
     }
     (void)hipMemsetAsync(vec, 0, (size_t)4 * large * 8, st_);
     (void)hipMemsetAsync(ag, 0, (size_t)agn_large * 8, st_);
