@@ -94,7 +94,8 @@ struct NdParams {
                                    // (measured on MI355X, profiles/r03_nd_leaf_merge_sweep.txt: 192 -> 384 saves 2 tree levels = 4 launches per
                                    // solve for +10 % of factor bytes; 768+ pays in the one-workgroup pivot-block inversion at setup)
     int top_merge_rows = 2048;     // the same cap for the root; halved per tree depth until it meets merge_rows
-    int max_pivot = 8192;          // largest pivot block (separator or unsplittable subgraph) accepted
+    int max_pivot = 8000;          // largest pivot block (separator or unsplittable subgraph) accepted: the batched Gauss-Jordan keeps one
+                                   // scaled pivot row of that many doubles in LDS (64 KB of dynamic LDS per workgroup, minus its reduction scratch)
     double max_dense_fraction = 0.25;  // refuse when the factors (above 256 MB) reach this share of the dense inverse's n^2 numbers: no separators worth the name
     size_t max_factor_bytes = (size_t)12 << 30;
     size_t max_front_bytes = (size_t)32 << 30;
