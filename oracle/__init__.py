@@ -2,6 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, ``__graft_entry__.smoke()`` and the
 ``cpu_baseline`` leg of bench.py.  Nothing under ``sparsh_amg_amd/`` imports this.
+Parity unpinned: see the header of oracle/amg_oracle.h and DESIGN.md section 2.
 """
 from __future__ import annotations
 

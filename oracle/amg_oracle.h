@@ -6,12 +6,15 @@
  * cpu_baseline leg of bench.py may load this library; the product
  * (sparsh_amg_amd/) never links, imports or calls it.
  *
- * Pinning: the reference holds no tests or golden vectors.  This restatement
- * is pinned against the residual histories the survey session captured from
- * the reference's own CPU sources (committed as
- * tests/golden/appendix_a.json).  The reference itself is NOT rebuilt here:
- * its CPU path needs mkl.h / PARDISO, which this image lacks, and building it
- * would need stand-in headers (see DESIGN.md "Oracle").
+ * PARITY UNPINNED (by this project's own rule): the reference holds no tests,
+ * fixtures or golden vectors for this path, and the reference itself cannot be
+ * built here (its CPU path needs mkl.h / PARDISO, which this image lacks; a
+ * build would need stand-in headers, which is not allowed).  What this
+ * restatement is held to are the residual histories the survey session
+ * captured from the reference's own CPU sources (SURVEY.md Appendix A,
+ * committed as tests/golden/appendix_a.json) -- but that session's build used
+ * a declarations-only mkl.h, so those numbers do not count as a pin either
+ * (see DESIGN.md section 2).
  *
  * Every function cites the reference file:line (relative to /root/reference)
  * whose arithmetic it follows.
