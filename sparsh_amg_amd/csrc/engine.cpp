@@ -1070,9 +1070,21 @@ int Engine::setup(const sparsh_params &p)
     dist_ = (G > 1 && repl_level_ > 0);
     if (dist_) gather_part_ = make_partition(H_.levels[repl_level_].A.nrow, G);
 
+    // SPARSH_SETUP_TIMING=1: where the device half of the setup spends its time (each phase synchronised)
+    const bool timing = std::getenv("SPARSH_SETUP_TIMING") != nullptr;
+    double t_phase = omp_get_wtime();
+    auto phase = [&](const char *what) {
+        if (!timing) return;
+        (void)hipDeviceSynchronize();
+        const double t = omp_get_wtime();
+        std::printf("setup timing: %-34s %.3f s\n", what, t - t_phase);
+        t_phase = t;
+    };
+    if (timing) std::printf("setup timing: %-34s %.3f s\n", "host hierarchy (+ direct-solver plan)", setup_seconds);
     lev_.assign((size_t)nl, DevLevel());
     int max_blk = 4096;
     for (int l = 0; l < nl; ++l) {
+        if (timing && l > 0) phase(("level " + std::to_string(l - 1) + ": layouts + uploads").c_str());
         const HostLevel &h = H_.levels[l];
         DevLevel &d = lev_[l];
         d.nglob = h.A.nrow;
@@ -1170,6 +1182,7 @@ int Engine::setup(const sparsh_params &p)
         if (!check(hipMemsetAsync(d.x2, 0, xcap * 8, st_), "hipMemsetAsync")) return SPARSH_ENODEV;
         if (!check(hipMemsetAsync(d.r, 0, rcap * 8, st_), "hipMemsetAsync")) return SPARSH_ENODEV;
     }
+    phase("last level: layouts + uploads");
     nL_ = H_.nL;
     if (H_.coarse_dense) {
         if (!coarse_.setup_dense(nL_, H_.coarse_inverse.data(), error)) return SPARSH_ENODEV;
@@ -1218,7 +1231,9 @@ int Engine::setup(const sparsh_params &p)
     }
     place_tried = 0;
     place_best_us = place_worst_us = place_first_us = 0.0;
+    phase("coarsest-level factorisation + workspace");
     if (G == 1 && cfg_.place_search) tune_placement();
+    phase("placement search");
     f32_ready_ = false;
     if (p.precond_fp32 && !setup_f32()) return SPARSH_EINVAL;
     if (dist_ && !st2_) {
