@@ -94,6 +94,15 @@ def _fem(npts):
     return problems.fem_unstructured(npts)
 
 
+def _squared(m):
+    """A^2 of the 7-pt operator: 25 entries per row, two-cell-wide couplings (what classical coarsening leaves behind): thicker separators."""
+    rp, ci, v = problems.poisson3d(m)
+    A = sp.csr_matrix((v, ci, rp))
+    B = (A @ A).tocsr()
+    B.sort_indices()
+    return B.indptr.astype(np.int32), B.indices.astype(np.int32), B.data.astype(np.float64)
+
+
 @pytest.mark.parametrize("name,gen,leaf,merge,top", [
     ("p3d_24", lambda: problems.poisson3d(24), 0, -1, -1),            # 13 824 rows, defaults (leaf 64, merged separators up to 384 rows, 2048 at the root)
     ("p3d_24_plain_bisection", lambda: problems.poisson3d(24), 16, 0, 0),   # small leaves, no merging: a deep tree
@@ -104,6 +113,7 @@ def _fem(npts):
     ("nonsym3d_22", lambda: _nonsym3d(22), 0, -1, -1),                 # not diagonally dominant: pivoting inside the pivot blocks
     ("p3d_ragged", lambda: problems.poisson3d(21), 32, 100, 300),
     ("fem_20000", lambda: _fem(20000), 0, -1, -1),                     # unstructured P1-FEM mesh: irregular separators, many children per node
+    ("p3d_22_squared", lambda: _squared(22), 0, -1, -1),              # 10 648 rows, 25 entries per row: two-cell-wide separators
     ("p3d_40_top_separator_above_1024_rows", lambda: problems.poisson3d(40), 0, -1, -1),  # 64 000 rows: the top pivot block takes the whole-chip inversion
 ])
 def test_nested_dissection_solver_vs_sparse_lu(name, gen, leaf, merge, top):
