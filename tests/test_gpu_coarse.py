@@ -135,7 +135,8 @@ def test_nested_dissection_solver_vs_sparse_lu(name, gen, leaf, merge, top):
         for b in (np.ones(n), rng.standard_normal(n)):
             x = A.op_coarse(b)
             xr = lu.solve(b)
-            assert np.linalg.norm(x - xr) <= 1e-11 * np.linalg.norm(xr), name
+            tol = 1e-10 if "squared" in name else 1e-11   # (the squared operator's condition number is the square: both solvers lose the digits)
+            assert np.linalg.norm(x - xr) <= tol * np.linalg.norm(xr), name
             # residual: within two orders of the sparse LU's own (explicit pivot-block inverses are forward-, not backward-stable; the FEM
             # operator's solution is 1e4 times its right-hand side, so eps ||A|| ||x|| counts: measured 13x the LU's 1.1e-9 there)
             assert np.linalg.norm(b - S @ x) <= max(1e-11 * np.linalg.norm(b), 100.0 * np.linalg.norm(b - S @ xr))
