@@ -295,12 +295,18 @@ def main():
         vectors; on level 0 it rides in cg_update) + residual + aggregation restrict / prolong, the coarsest solve, and on
         level 0 the Krylov step: SpMV with the p.Ap dot, cg_update (p, Ap, x, r, d read; x, r, z written), p update."""
         total = 0
+        prev_paired = False
         for l, (nl, nnzl, pn, pnnz) in enumerate(levels[:-1]):
             ncl = levels[l + 1][0]
-            total += (2 * sweeps - 1) * layout_bytes(H, nl, nnzl, l, 3) + layout_bytes(H, nl, nnzl, l, 3)
-            if l > 0:
+            total += (2 * sweeps - 1) * layout_bytes(H, nl, nnzl, l, 3)
+            if l > 0 and not prev_paired:
                 total += 24 * nl
-            total += (4 * (ncl + 1) + 4 * pnnz + 8 * nl + 8 * ncl) + (4 * nl + 8 * ncl + 16 * nl)
+            prev_paired = H.level_paired(l)
+            if prev_paired:  # residual + restriction + the coarse zero-guess sweep in one launch: x, b in; b_c, x_c out, d_c in
+                total += layout_bytes(H, nl, nnzl, l, 2) + 24 * ncl
+            else:
+                total += layout_bytes(H, nl, nnzl, l, 3) + (4 * (ncl + 1) + 4 * pnnz + 8 * nl + 8 * ncl)
+            total += 4 * nl + 8 * ncl + 16 * nl
         total += coarse["bytes"] + 16 * levels[-1][0]
         n0, nnz0 = levels[0][0], levels[0][1]
         total += layout_bytes(H, n0, nnz0, 0, 2) + 64 * n0 + 24 * n0
@@ -671,6 +677,8 @@ def main():
                                    f"{coarse['form']} direct solve; the reference itself would hand {levels[5][0] if len(levels) > 5 else levels[-1][0]} rows to PARDISO")
                                   if coarse["extended"] else "the reference's own policy: level1 = 6 levels, the rest to the direct solver"),
                 "coarsest_level": coarse,
+                # levels whose residual, restriction and the next level's zero-guess sweep are one launch (aggregates = row pairs 2J, 2J+1)
+                "paired_restriction_levels": [l for l in range(len(levels) - 1) if A.level_paired(l)],
                 "parallelism": "1 GPU" if world == 1 else (mode_note or (
                     f"{world} GPUs, one process each: contiguous row blocks on the {partitioned_levels} finest levels; deep-halo smoothing "
                     f"(sweeps+1 ghost layers per block, ONE ghost-layer exchange per smoothing leg, grouped ncclSend/ncclRecv of packed "

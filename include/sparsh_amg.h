@@ -161,6 +161,15 @@ int sparsh_set_index_compression(sparsh_handle h, int mode);
  * 640 MB = 2.5x the Infinity Cache (matrix-streaming layouts of large levels: -3...6 % per sweep; smaller levels and the
  * value-free table path measured neutral within +-1 %); 2: always alternate (A/B). */
 int sparsh_set_alternate_sweeps(sparsh_handle h, int mode);
+/* On a lexicographically ordered grid the aggregation (HEM, src/AMG_coarsening.cpp) joins rows 2J and 2J+1 on most
+ * levels.  There the residual kernel of the table path hands each row's residual to the lane next door, adds the pair in the
+ * order transfer_residual does and writes the coarse right-hand side and the coarse level's zero-guess sweep directly: the
+ * level's residual vector is neither written nor read back and one launch replaces two (parallel::store_residual +
+ * parallel::transfer_residual, src/AMG_cycle_utilities.cpp:115-123 and :97-104).  Same expressions in the same order --
+ * results are bitwise unchanged.  enable: 1 (default) / 0 (A/B).
+ * sparsh_level_paired: whether a level of the built hierarchy takes this path under the current configuration. */
+int sparsh_set_paired_restriction(sparsh_handle h, int enable);
+int sparsh_level_paired(sparsh_handle h, int level, int *paired);
 /* PCG: the x / r update kernel also writes the zero-guess sweep z0 = omega r / d of the V-cycle that follows (same bits, one
  * read of r and one launch less), and streams x, p, Ap and d past the caches (non-temporal loads / stores) so that r and z0,
  * which the cycle's first sweep reads next, are what stays resident.  mode 2 (default): both; 1: fused, ordinary loads;
@@ -303,6 +312,9 @@ int sparsh_op_jacobi(sparsh_handle h, int level, const double *b, double *x, int
 int sparsh_op_residual(sparsh_handle h, int level, const double *b, const double *x, double *r);
 int sparsh_op_resnorm(sparsh_handle h, int level, const double *b, const double *x, double *nrm);
 int sparsh_op_restrict(sparsh_handle h, int level, const double *r, double *bc);
+/* levels sparsh_level_paired reports: bc = P_l^T (b - A_l x) and xc = omega bc / d_{l+1} from the one fused launch the
+ * V-cycle uses there (store_residual + transfer_residual + the coarse level's first sweep from a zero guess) */
+int sparsh_op_residual_restrict(sparsh_handle h, int level, const double *b, const double *x, double *bc, double *xc);
 int sparsh_op_prolong(sparsh_handle h, int level, const double *xc, double *xf);
 int sparsh_op_coarse(sparsh_handle h, const double *b, double *x);
 /* z = V32(r): one application of the opt-in fp32 preconditioner (params.precond_fp32 = 1): a V(nu,nu) cycle from a

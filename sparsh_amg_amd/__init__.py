@@ -91,6 +91,8 @@ def _load():
         "sparsh_set_tile": (C.c_int, [H, C.c_int]),
         "sparsh_set_index_compression": (C.c_int, [H, C.c_int]),
         "sparsh_set_alternate_sweeps": (C.c_int, [H, C.c_int]),
+        "sparsh_set_paired_restriction": (C.c_int, [H, C.c_int]),
+        "sparsh_level_paired": (C.c_int, [H, C.c_int, C.POINTER(C.c_int)]),
         "sparsh_set_fused_zero_sweep": (C.c_int, [H, C.c_int]),
         "sparsh_set_placement_search": (C.c_int, [H, C.c_int]),
         "sparsh_placement_info": (C.c_int, [H, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), c_int_p, C.POINTER(C.c_double)]),
@@ -150,6 +152,7 @@ def _load():
         "sparsh_op_residual": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p]),
         "sparsh_op_resnorm": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p]),
         "sparsh_op_restrict": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p]),
+        "sparsh_op_residual_restrict": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p]),
         "sparsh_op_prolong": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p]),
         "sparsh_op_coarse": (C.c_int, [H, c_dbl_p, c_dbl_p]),
         "sparsh_op_dot": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p]),
@@ -326,6 +329,17 @@ class sp_matrix_mg:
         """Alternate the walking direction of consecutive sweeps of a smoothing leg: 0 never, 1 large streaming levels (default), 2 always."""
         _check(lib.sparsh_set_alternate_sweeps(self._h, int(mode)))
         return self
+
+    def set_paired_restriction(self, enable=True):
+        """Residual + restriction (+ the coarse zero-guess sweep) as one launch on levels whose aggregates are the row pairs (2J, 2J+1)."""
+        _check(lib.sparsh_set_paired_restriction(self._h, 1 if enable else 0))
+        return self
+
+    def level_paired(self, level):
+        """Whether `level` of the built hierarchy takes the fused residual + restriction launch."""
+        v = C.c_int(0)
+        _check(lib.sparsh_level_paired(self._h, int(level), C.byref(v)))
+        return bool(v.value)
 
     def set_index_compression(self, mode=1):
         """16-bit delta-coded column indices for the CSR-stream family (call before setup); see sparsh_set_index_compression."""
@@ -696,6 +710,15 @@ class sp_matrix_mg:
         bc = np.zeros(self.level_info(level + 1)["nrow"])
         _check(lib.sparsh_op_restrict(self._h, level, _dp(r), _dp(bc)))
         return bc
+
+    def op_residual_restrict(self, level, b, x):
+        """(b_{l+1}, x_{l+1}) of the fused residual + restriction launch (levels where level_paired() is true)."""
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        nc = self.level_info(level + 1)["nrow"]
+        bc, xc = np.zeros(nc), np.zeros(nc)
+        _check(lib.sparsh_op_residual_restrict(self._h, level, _dp(b), _dp(x), _dp(bc), _dp(xc)))
+        return bc, xc
 
     def op_prolong(self, level, xc, xf):
         xc = np.ascontiguousarray(xc, dtype=np.float64)

@@ -410,6 +410,23 @@ int sparsh_set_alternate_sweeps(sparsh_handle h, int enable)
     return SPARSH_OK;
 }
 
+int sparsh_set_paired_restriction(sparsh_handle h, int enable)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    h->eng->kernel_cfg().pair_restrict = enable != 0;
+    h->eng->config_changed();
+    return SPARSH_OK;
+}
+
+int sparsh_level_paired(sparsh_handle h, int level, int *paired)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    if (!paired) return fail(SPARSH_EINVAL, "null output");
+    *paired = h->eng->level_paired(level) ? 1 : 0;
+    return SPARSH_OK;
+}
+
 int sparsh_set_index_compression(sparsh_handle h, int mode)
 {
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
@@ -965,6 +982,20 @@ int sparsh_op_restrict(sparsh_handle h, int level, const double *r, double *bc)
     DBuf dr(E, (size_t)E.level(level).n, r), dc(E, (size_t)E.level(level + 1).n);
     E.op_restrict(level, dr.p, dc.p);
     return done(E, dc.get(bc));
+}
+
+int sparsh_op_residual_restrict(sparsh_handle h, int level, const double *b, const double *x, double *bc, double *xc)
+{
+    REQUIRE_READY(h);
+    REQUIRE_SINGLE(h);
+    REQUIRE_LEVEL(h, level);
+    Engine &E = *h->eng;
+    if (!E.level_paired(level)) return fail(SPARSH_ESTATE, "the level does not take the fused residual + restriction launch (sparsh_level_paired)");
+    DBuf db(E, (size_t)E.level(level).n, b), dx(E, (size_t)E.level(level).A.ncol, x);
+    DBuf dc(E, (size_t)E.level(level + 1).n), dz(E, (size_t)E.level(level + 1).n);
+    E.op_residual_restrict(level, db.p, dx.p, dc.p, dz.p);
+    const int rc = done(E, dc.get(bc));
+    return rc != SPARSH_OK ? rc : done(E, dz.get(xc));
 }
 
 int sparsh_op_prolong(sparsh_handle h, int level, const double *xc, double *xf)

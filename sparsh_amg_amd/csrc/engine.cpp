@@ -1098,6 +1098,15 @@ int Engine::setup(const sparsh_params &p)
             if (l + 1 < nl) {
                 if (!upload_csr(*this, h.P, d.P, false) || !upload_csr(*this, h.R, d.R, false)) return SPARSH_ENODEV;
                 d.P_is_aggregation = h.P_is_aggregation;
+                if (h.P_is_aggregation && !dist_) {
+                    // HEM pairs neighbours along the first grid line on most levels of a lexicographically ordered grid:
+                    // aggregate J = rows (2J, 2J+1) (a last single row when n is odd), listed in that order by R
+                    const int n = h.A.nrow, nc = h.R.nrow;
+                    bool pairs = nc == (n + 1) / 2 && h.R.rowptr[nc] == n && h.P.rowptr[n] == n;
+                    for (int J = 0; pairs && J < nc; ++J) pairs = h.R.rowptr[J] == 2 * J;
+                    for (int j = 0; pairs && j < n; ++j) pairs = h.R.col[j] == j && h.P.col[j] == j / 2;
+                    d.pair_aggregates = pairs;
+                }
             }
             xcap = rcap = (size_t)d.n;
         } else {
@@ -1481,6 +1490,18 @@ void Engine::op_residual(int l, const double *b, const double *x, double *r)
     apply_A(lev_[l], OP_RESID, a);
 }
 
+void Engine::op_residual_restrict(int l, const double *b, const double *x, double *bc, double *xc)
+{
+    CsrArgs a;
+    a.x = x;
+    a.b = b;
+    a.y = bc;
+    a.y2 = xc;
+    a.d = lev_[l + 1].diag;
+    a.omega = prm_.omega;
+    launch_resid_pair(lev_[l].A, a, lev_[l].fine, st_, cfg_);
+}
+
 double Engine::op_resnorm(int l, const double *b, const double *x)
 {
     CsrArgs a;
@@ -1666,6 +1687,12 @@ void Engine::vcycle(const double *b0, bool x0_zero, double *dot_partial, int *do
             continue;
         }
         smooth(L, L.b, nu, l > 0 || x0_zero, nullptr, nullptr, zero_done);  // coarse levels start from x = 0 (fill, :204)
+        if (level_paired(l)) {
+            // store_residual + transfer_residual (+ x_{l+1} = omega*b/d) in one launch: r_l never goes to memory
+            op_residual_restrict(l, L.b, L.x, lev_[l + 1].b, lev_[l + 1].x);
+            zero_done = true;
+            continue;
+        }
         op_residual(l, L.b, L.x, L.r);                                      // store_residual
         zero_done = op_restrict(l, L.r, lev_[l + 1].b, nu > 0);             // transfer_residual (+ x_{l+1} = omega*b/d)
     }

@@ -34,6 +34,7 @@ struct DevLevel {
     DevPlan planA, planP, planR;  // halo plans of A_l x, P_l x_{l+1}, R_l r_l (empty on one GPU)
     DevCsr A, P, R;
     bool P_is_aggregation = false;
+    bool pair_aggregates = false;  // aggregate J = fine rows (2J, 2J+1) in R's stored order: residual + restriction fuse (OP_RESID_PAIR)
     double *diag = nullptr;
     double *x = nullptr, *x2 = nullptr;  // ping-pong solution buffers (Jacobi reads old, writes new)
     double *b = nullptr;                 // rhs of this level (level 0: points at the caller's vector)
@@ -101,6 +102,11 @@ public:
     const KernelConfig &kernel_cfg() const { return cfg_; }
     // a captured hipGraph of the iteration replays the kernels of the configuration it was captured under: drop it
     void config_changed() { drop_graph(); }
+    // whether level l's residual, restriction and the next level's zero-guess sweep run as one launch (OP_RESID_PAIR)
+    bool level_paired(int l) const
+    {
+        return l + 2 < (int)lev_.size() && lev_[l].pair_aggregates && prm_.sweeps > 0 && !dist_ && resid_pair_applies(lev_[l].A, cfg_);
+    }
     // average seconds of one communication step alone (collective: every rank calls it): what = 0 halo
     // exchange of level `level`'s operator, 1 the 16-byte all-reduce of the fused scalars, 2 the
     // all-gather at the partitioned -> replicated boundary.  -1 when the step does not exist.
@@ -174,6 +180,8 @@ public:
     double op_resnorm(int l, const double *b, const double *x);
     // fuse_zero: also write the coarse level's zero-guess sweep (aggregation P, no gather step); returns whether it did
     bool op_restrict(int l, const double *r, double *bc, bool fuse_zero = false);
+    // level_paired(l) levels: b_{l+1} = R (b - A x) and x_{l+1} = omega b_{l+1} / d_{l+1} in one launch
+    void op_residual_restrict(int l, const double *b, const double *x, double *bc, double *xc);
     void op_prolong(int l, const double *xc, double *xf);
     void op_coarse(const double *b, double *x);
     // z = V32(r): one application of the opt-in fp32 preconditioner (fp64 in/out); needs precond_fp32

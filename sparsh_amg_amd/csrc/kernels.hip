@@ -114,7 +114,7 @@ __device__ __forceinline__ int ld_stream(const int *p)
 //  * sell_kernel (kind 2): sliced-ELL mirror, lane = row, no LDS: every load of a wave is one
 //    contiguous segment (and for stencil matrices so is the x gather).
 
-constexpr bool op_needs_b(int OP) { return OP == OP_RESID || OP == OP_JACOBI || OP == OP_JACOBI_DOT || OP == OP_RESNORM; }
+constexpr bool op_needs_b(int OP) { return OP == OP_RESID || OP == OP_JACOBI || OP == OP_JACOBI_DOT || OP == OP_RESNORM || OP == OP_RESID_PAIR; }
 constexpr bool op_needs_d(int OP) { return OP == OP_JACOBI || OP == OP_JACOBI_DOT; }
 constexpr bool op_needs_xi(int OP) { return OP == OP_JACOBI || OP == OP_JACOBI_DOT || OP == OP_SPMV_DOT; }
 constexpr bool op_reduces(int OP) { return OP == OP_SPMV_DOT || OP == OP_RESNORM || OP == OP_JACOBI_DOT; }
@@ -1028,6 +1028,10 @@ __global__ __launch_bounds__(kBlock) void sdia_tab_kernel(int nrow, int xlen, in
         double sum = 0.0;
         RowOperands o;
         double dv = 0.0;
+        double dpair = 1.0;  // RESID_PAIR: diagonal of the coarse row this even lane writes (in flight beside the gathers)
+        if constexpr (OP == OP_RESID_PAIR) {
+            if (has_row && !(lane & 1)) dpair = a.d[row >> 1];
+        }
         // lexicographic grid stencils: -1, 0, +1 in adjacent slots (launch-uniform test on kernel arguments)
         const int near = tab.near;
         if (near) {
@@ -1057,7 +1061,21 @@ __global__ __launch_bounds__(kBlock) void sdia_tab_kernel(int nrow, int xlen, in
             if constexpr (op_needs_xi(OP)) o.xi = a.x[row];
             sum = sdia_offtable_row<NT>(sl, row, lane, a.x, sd_ptr, sd_off, sd_mask, sd_vidx, sd_cval, sd_val, sd_rec, o.di);
         }
-        if (has_row) acc = row_epilogue<OP>(a, row, sum, o);
+        if constexpr (OP == OP_RESID_PAIR) {
+            // aggregates are the row pairs (2J, 2J+1) and a slice starts on an even row: the partner's residual comes
+            // from the lane above.  Same expressions, same order as OP_RESID + restrict_agg_zero_kernel:
+            // r = 1.0*b + (-1.0)*s ; b_c = (0 + r_2J) + r_2J+1 ; x_c = omega*b_c/d_c
+            const double ri = has_row ? 1.0 * o.bi + (-1.0) * sum : 0.0;
+            const double rn = lane_from_above(ri, 0.0);
+            if (has_row && !(lane & 1)) {
+                double bc = 0.0 + ri;
+                if (row + 1 < nrow) bc = bc + rn;
+                a.y[row >> 1] = bc;
+                a.y2[row >> 1] = a.omega * bc / dpair;
+            }
+        } else {
+            if (has_row) acc = row_epilogue<OP>(a, row, sum, o);
+        }
     }
     if constexpr (op_reduces(OP)) {
         const double t = block_sum(acc, red);
@@ -1424,6 +1442,24 @@ int launch_csr_tagged(const DevCsr &A, const CsrArgs &a, bool nt, int remap, hip
 }
 
 }  // namespace
+
+bool resid_pair_applies(const DevCsr &A, const KernelConfig &c)
+{
+    return c.pair_restrict && csr_family(A, c) == FAM_SDIA_TAB && sdia_tile_rows(A, c) == 0 && A.nslice > 0;
+}
+
+void launch_resid_pair(const DevCsr &A, const CsrArgs &a, bool finest, hipStream_t st, const KernelConfig &c)
+{
+    bool nt;
+    int remap;
+    csr_placement(A, c, &nt, &remap);
+    const int ngroups = (A.nslice + 3) / 4;
+    const int grid = remap_grid(ngroups, remap);
+    if (finest)
+        hipLaunchKernelGGL((sdia_tab_kernel<OP_RESID_PAIR, false, 1>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.ncol, A.nslice, ngroups, remap, A.sd_tab, nullptr, A.sd_tmask, A.sd_tconf, A.sd_ptr, A.sd_off, A.sd_mask, A.sd_vidx, A.sd_cval, A.sd_val, A.sd_rec, a);
+    else
+        hipLaunchKernelGGL((sdia_tab_kernel<OP_RESID_PAIR, false, 0>), dim3(grid), dim3(kBlock), 0, st, A.nrow, A.ncol, A.nslice, ngroups, remap, A.sd_tab, nullptr, A.sd_tmask, A.sd_tconf, A.sd_ptr, A.sd_off, A.sd_mask, A.sd_vidx, A.sd_cval, A.sd_val, A.sd_rec, a);
+}
 
 CsrFamily csr_family(const DevCsr &A, const KernelConfig &c)
 {
@@ -1931,6 +1967,7 @@ int launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool finest, hipStre
     case OP_SPMV_DOT: return launch_csr_op<OP_SPMV_DOT>(A, a, finest, st, cfg);
     case OP_RESNORM: return launch_csr_op<OP_RESNORM>(A, a, finest, st, cfg);
     case OP_JACOBI_DOT: return launch_csr_op<OP_JACOBI_DOT>(A, a, finest, st, cfg);
+    case OP_RESID_PAIR: break;  // table kernel only: launch_resid_pair
     }
     return 0;
 }

@@ -100,6 +100,8 @@ struct KernelConfig {
     bool fuse_cg_zero = true; // PCG: the cg_update kernel also writes the V-cycle's zero-guess sweep of level 0
     int alt_dir = 1;          // consecutive sweeps of a smoothing leg walk the level in alternating directions (CsrArgs::reverse):
                               // 0 never, 1 where a sweep streams more than 640 MB (2.5x the Infinity Cache), 2 always
+    bool pair_restrict = true; // V-cycle: on levels whose aggregates are the row pairs (2J, 2J+1) the residual kernel also
+                               // restricts and writes the coarse level's zero-guess sweep (OP_RESID_PAIR)
     int idx16 = 1;      // layout option read at setup: build the 16-bit delta column form (DevCsr::col16) for 0 no operator,
                         // 1 operators whose default family is the CSR-stream kernel streaming from HBM, 2 every operator
 };
@@ -125,7 +127,10 @@ enum CsrOp : int {
     OP_ADD = 3,       // y_i = s_i + y_i                          (transfer_solution, beta = 1)
     OP_SPMV_DOT = 4,  // y_i = s_i ; partial += x_i*s_i           (Ap and p.Ap of CG)
     OP_RESNORM = 5,   // partial += (s_i - b_i)^2                 (residual norm, nothing stored)
-    OP_JACOBI_DOT = 6 // Jacobi sweep ; partial += y_i*b_i        (last post-sweep of PCG: z.r)
+    OP_JACOBI_DOT = 6, // Jacobi sweep ; partial += y_i*b_i        (last post-sweep of PCG: z.r)
+    OP_RESID_PAIR = 7  // levels whose aggregates are the row pairs (2J, 2J+1): y_J = (b - s)_2J + (b - s)_2J+1 and
+                       // y2_J = omega*y_J/d_J -- residual, restriction and the coarse level's zero-guess sweep in one
+                       // launch (table kernel only: launch_resid_pair)
 };
 
 struct CsrArgs {
@@ -133,6 +138,7 @@ struct CsrArgs {
     const double *b = nullptr;   // rhs (RESID/JACOBI/RESNORM)
     const double *d = nullptr;   // diagonal (JACOBI)
     double *y = nullptr;         // output
+    double *y2 = nullptr;        // second output (RESID_PAIR: the coarse level's zero-guess sweep; d is then the coarse diagonal)
     double omega = 0.0;
     double *partial = nullptr;   // per-block partial sums (reductions), size >= nblk
     // optional subset launch of the sliced kernels (multi-GPU overlap): process only the slices
@@ -158,6 +164,10 @@ int build_col16(const int *rowptr, const int *col, const int *rec, int nblk, uns
 // `finest`: launch on the finest level (selects a separately named kernel instance for profilers)
 int launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool finest, hipStream_t st, const KernelConfig &cfg);
 CsrFamily csr_family(const DevCsr &A, const KernelConfig &cfg);
+// OP_RESID_PAIR over the whole of A (a.y = coarse rhs, a.y2 = coarse iterate, a.d = coarse diagonal); applies to operators
+// that run the table kernel under cfg -- resid_pair_applies says whether launch_resid_pair may be called
+bool resid_pair_applies(const DevCsr &A, const KernelConfig &cfg);
+void launch_resid_pair(const DevCsr &A, const CsrArgs &a, bool finest, hipStream_t st, const KernelConfig &cfg);
 // whether consecutive sweeps over A alternate their walking direction under cfg (KernelConfig::alt_dir)
 bool csr_alternates(const DevCsr &A, const KernelConfig &cfg);
 const char *csr_family_name(CsrFamily f);

@@ -645,3 +645,58 @@ def test_few_sweeps_pcg_matches_oracle(nu):
         h2, _ = A.solve("pcg", b, x2)
         assert np.array_equal(h2, h) and np.array_equal(x2, x)
     A.close()
+
+
+def _line1d(n):
+    import scipy.sparse as sp
+
+    T = sp.diags([-np.ones(n - 1), 2.0 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1], format="csr")
+    return T.indptr.astype(np.int32), T.indices.astype(np.int32), T.data
+
+
+@pytest.mark.parametrize("name,gen", [
+    ("p3d_30", lambda: problems.poisson3d(30)),
+    ("p2d_150", lambda: problems.poisson2d(150)),
+    ("line_40001", lambda: _line1d(40001)),  # odd row count: the last aggregate is a single row; levels 0 and 2 pair
+    ("line_40000", lambda: _line1d(40000)),
+])
+def test_paired_restriction_bitwise(name, gen):
+    """Levels whose aggregates are the row pairs (2J, 2J+1) run store_residual + transfer_residual + the coarse level's
+    zero-guess sweep as one launch (OP_RESID_PAIR).  Against the oracle's three separate steps, bit for bit, on every
+    such level; and whole solves with the fusion on and off give the same histories and solutions, bit for bit."""
+    rp, ci, v = gen()
+    n = len(rp) - 1
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET, max_iter=40))  # (the line problems need more: capped)
+    O = oracle.Csr(rp, ci, v)
+    H = oracle.Hierarchy(O)
+    rng = np.random.default_rng(77)
+    paired = [l for l in range(A.nlevels - 1) if A.level_paired(l)]
+    assert 0 in paired, (name, paired)
+    assert not A.level_paired(A.nlevels - 2)  # the level above the coarsest keeps the plain restriction (no sweep there)
+    for l in paired:
+        nl = A.level_info(l)["nrow"]
+        x, b = rng.standard_normal(nl), rng.standard_normal(nl)
+        r = oracle.store_residual(H.A(l), b, x)
+        bc_o = oracle.transfer_residual(H.P(l), r)
+        xc_o = oracle.jacobi(H.A(l + 1), bc_o, np.zeros(len(bc_o)), 0)
+        bc, xc = A.op_residual_restrict(l, b, x)
+        assert np.array_equal(bc, bc_o), (name, l)
+        assert np.array_equal(xc, xc_o), (name, l)
+        assert np.array_equal(bc, A.op_restrict(l, A.op_residual(l, b, x))), (name, l)
+    b = rng.standard_normal(n)
+    out = {}
+    for on in (True, False):
+        A.set_paired_restriction(on)
+        assert (0 in [l for l in range(A.nlevels - 1) if A.level_paired(l)]) == on
+        for method in ("amg", "pcg", "pbicg"):
+            x = np.zeros(n)
+            h, rc = A.solve(method, b, x)
+            assert rc in (0, sa.SPARSH_ENOCONV) and len(h) > 0
+            out[(on, method)] = (np.array(h), x)
+    for method in ("amg", "pcg", "pbicg"):
+        assert np.array_equal(out[(True, method)][0], out[(False, method)][0]), (name, method)
+        assert np.array_equal(out[(True, method)][1], out[(False, method)][1]), (name, method)
+    A.set_paired_restriction(False)
+    with pytest.raises(Exception):
+        A.op_residual_restrict(0, b, b)
+    A.close()
