@@ -306,7 +306,12 @@ def main():
                 total += layout_bytes(H, nl, nnzl, l, 2) + 24 * ncl
             else:
                 total += layout_bytes(H, nl, nnzl, l, 3) + (4 * (ncl + 1) + 4 * pnnz + 8 * nl + 8 * ncl)
-            total += 4 * nl + 8 * ncl + 16 * nl
+            form = H.level_prolong_fused(l + 1)
+            if form:  # level l+1's last post-sweep adds its result to x_l itself: x_l read + written, (first, second) records unless the
+                      # aggregates are the row pairs; that sweep does not store its own result
+                total += 16 * nl + (8 * ncl if form == 2 else 0) - 8 * ncl
+            else:
+                total += 4 * nl + 8 * ncl + 16 * nl
         total += coarse["bytes"] + 16 * levels[-1][0]
         n0, nnz0 = levels[0][0], levels[0][1]
         total += layout_bytes(H, n0, nnz0, 0, 2) + 64 * n0 + 24 * n0
@@ -679,6 +684,8 @@ def main():
                 "coarsest_level": coarse,
                 # levels whose residual, restriction and the next level's zero-guess sweep are one launch (aggregates = row pairs 2J, 2J+1)
                 "paired_restriction_levels": [l for l in range(len(levels) - 1) if A.level_paired(l)],
+                # levels whose last post-sweep prolongates into the level above itself (no prolongation launch)
+                "fused_prolongation_levels": [l for l in range(len(levels)) if A.level_prolong_fused(l)],
                 "parallelism": "1 GPU" if world == 1 else (mode_note or (
                     f"{world} GPUs, one process each: contiguous row blocks on the {partitioned_levels} finest levels; deep-halo smoothing "
                     f"(sweeps+1 ghost layers per block, ONE ghost-layer exchange per smoothing leg, grouped ncclSend/ncclRecv of packed "

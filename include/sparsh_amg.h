@@ -169,6 +169,15 @@ int sparsh_set_alternate_sweeps(sparsh_handle h, int mode);
  * results are bitwise unchanged.  enable: 1 (default) / 0 (A/B).
  * sparsh_level_paired: whether a level of the built hierarchy takes this path under the current configuration. */
 int sparsh_set_paired_restriction(sparsh_handle h, int enable);
+/* Up-leg: with an aggregation prolongator every fine row has exactly one coarse owner, so the last post-smoothing sweep of
+ * level l can add its result to the rows of level l - 1 it owns (x_f = 1.0 * x_c + x_f, parallel::transfer_solution,
+ * src/AMG_cycle_utilities.cpp:107-112) instead of storing it for a prolongation launch: one launch and one pass over the
+ * coarse iterate less per level.  Used where the aggregates hold one or two rows (pairwise matching), on one GPU.  Same
+ * expressions -- results are bitwise unchanged.  enable: 1 (default) / 0 (A/B).
+ * sparsh_level_prolong_fused: whether level `level`'s last post-sweep prolongates into level - 1 itself: 0 no, 1 yes with
+ * the aggregates being the row pairs (2J, 2J+1) (no index read), 2 yes through an 8-byte (first, second) record per aggregate. */
+int sparsh_set_fused_prolongation(sparsh_handle h, int enable);
+int sparsh_level_prolong_fused(sparsh_handle h, int level, int *fused);
 int sparsh_level_paired(sparsh_handle h, int level, int *paired);
 /* PCG: the x / r update kernel also writes the zero-guess sweep z0 = omega r / d of the V-cycle that follows (same bits, one
  * read of r and one launch less), and streams x, p, Ap and d past the caches (non-temporal loads / stores) so that r and z0,
@@ -316,6 +325,9 @@ int sparsh_op_restrict(sparsh_handle h, int level, const double *r, double *bc);
  * V-cycle uses there (store_residual + transfer_residual + the coarse level's first sweep from a zero guess) */
 int sparsh_op_residual_restrict(sparsh_handle h, int level, const double *b, const double *x, double *bc, double *xc);
 int sparsh_op_prolong(sparsh_handle h, int level, const double *xc, double *xf);
+/* levels sparsh_level_prolong_fused reports: xf (level - 1, in/out) += P_{level-1} J(x), J = one Jacobi sweep of `level`
+ * from x with right-hand side b -- the one launch the V-cycle's up-leg uses there */
+int sparsh_op_jacobi_prolong(sparsh_handle h, int level, const double *b, const double *x, double *xf);
 int sparsh_op_coarse(sparsh_handle h, const double *b, double *x);
 /* z = V32(r): one application of the opt-in fp32 preconditioner (params.precond_fp32 = 1): a V(nu,nu) cycle from a
  * zero guess on the float copy of the hierarchy, fp64 in/out.  Checked against oracle_vcycle_f32. */

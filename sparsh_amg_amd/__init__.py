@@ -92,6 +92,9 @@ def _load():
         "sparsh_set_index_compression": (C.c_int, [H, C.c_int]),
         "sparsh_set_alternate_sweeps": (C.c_int, [H, C.c_int]),
         "sparsh_set_paired_restriction": (C.c_int, [H, C.c_int]),
+        "sparsh_set_fused_prolongation": (C.c_int, [H, C.c_int]),
+        "sparsh_level_prolong_fused": (C.c_int, [H, C.c_int, C.POINTER(C.c_int)]),
+        "sparsh_op_jacobi_prolong": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p]),
         "sparsh_level_paired": (C.c_int, [H, C.c_int, C.POINTER(C.c_int)]),
         "sparsh_set_fused_zero_sweep": (C.c_int, [H, C.c_int]),
         "sparsh_set_placement_search": (C.c_int, [H, C.c_int]),
@@ -329,6 +332,25 @@ class sp_matrix_mg:
         """Alternate the walking direction of consecutive sweeps of a smoothing leg: 0 never, 1 large streaming levels (default), 2 always."""
         _check(lib.sparsh_set_alternate_sweeps(self._h, int(mode)))
         return self
+
+    def set_fused_prolongation(self, enable=True):
+        """The last post-sweep of a level adds its result to the finer level's iterate itself (aggregates of one or two rows)."""
+        _check(lib.sparsh_set_fused_prolongation(self._h, 1 if enable else 0))
+        return self
+
+    def level_prolong_fused(self, level):
+        """Whether `level`'s last post-sweep prolongates into level - 1 itself: 0 no, 1 row pairs (2J, 2J+1), 2 member records."""
+        v = C.c_int(0)
+        _check(lib.sparsh_level_prolong_fused(self._h, int(level), C.byref(v)))
+        return v.value
+
+    def op_jacobi_prolong(self, level, b, x, xf):
+        """xf + P_{level-1} J(x) through the fused launch (levels where level_prolong_fused() is true)."""
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        xf = np.array(xf, dtype=np.float64)
+        _check(lib.sparsh_op_jacobi_prolong(self._h, int(level), _dp(b), _dp(x), _dp(xf)))
+        return xf
 
     def set_paired_restriction(self, enable=True):
         """Residual + restriction (+ the coarse zero-guess sweep) as one launch on levels whose aggregates are the row pairs (2J, 2J+1)."""

@@ -410,6 +410,23 @@ int sparsh_set_alternate_sweeps(sparsh_handle h, int enable)
     return SPARSH_OK;
 }
 
+int sparsh_set_fused_prolongation(sparsh_handle h, int enable)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    h->eng->kernel_cfg().fuse_prolong = enable != 0;
+    h->eng->config_changed();
+    return SPARSH_OK;
+}
+
+int sparsh_level_prolong_fused(sparsh_handle h, int level, int *fused)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    if (!fused) return fail(SPARSH_EINVAL, "null output");
+    *fused = !h->eng->level_prolong_fused(level) ? 0 : (h->eng->level(level - 1).pair_aggregates ? 1 : 2);
+    return SPARSH_OK;
+}
+
 int sparsh_set_paired_restriction(sparsh_handle h, int enable)
 {
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
@@ -996,6 +1013,18 @@ int sparsh_op_residual_restrict(sparsh_handle h, int level, const double *b, con
     E.op_residual_restrict(level, db.p, dx.p, dc.p, dz.p);
     const int rc = done(E, dc.get(bc));
     return rc != SPARSH_OK ? rc : done(E, dz.get(xc));
+}
+
+int sparsh_op_jacobi_prolong(sparsh_handle h, int level, const double *b, const double *x, double *xf)
+{
+    REQUIRE_READY(h);
+    REQUIRE_SINGLE(h);
+    REQUIRE_LEVEL(h, level);
+    Engine &E = *h->eng;
+    if (!E.level_prolong_fused(level)) return fail(SPARSH_ESTATE, "the level's last post-sweep does not prolongate itself (sparsh_level_prolong_fused)");
+    DBuf db(E, (size_t)E.level(level).n, b), dx(E, (size_t)E.level(level).A.ncol, x), df(E, (size_t)E.level(level - 1).n, xf);
+    E.op_jacobi_prolong(level, db.p, dx.p, df.p);
+    return done(E, df.get(xf));
 }
 
 int sparsh_op_prolong(sparsh_handle h, int level, const double *xc, double *xf)

@@ -1106,6 +1106,19 @@ int Engine::setup(const sparsh_params &p)
                     for (int J = 0; pairs && J < nc; ++J) pairs = h.R.rowptr[J] == 2 * J;
                     for (int j = 0; pairs && j < n; ++j) pairs = h.R.col[j] == j && h.P.col[j] == j / 2;
                     d.pair_aggregates = pairs;
+                    if (!pairs && nc > 0) {  // aggregates of one or two rows (pairwise matching): their rows, for the fused prolongation
+                        std::vector<int> mem((size_t)2 * nc, -1);
+                        bool two = h.R.rowptr[nc] == n && h.P.rowptr[n] == n;
+                        for (int J = 0; two && J < nc; ++J) {
+                            const int j0 = h.R.rowptr[J], len = h.R.rowptr[J + 1] - j0;
+                            two = len == 1 || len == 2;
+                            if (!two) break;
+                            mem[(size_t)2 * J] = h.R.col[j0];
+                            if (len == 2) mem[(size_t)2 * J + 1] = h.R.col[j0 + 1];
+                            for (int q = 0; q < len; ++q) two = two && h.P.col[h.R.col[j0 + q]] == J;
+                        }
+                        if (two) d.members = upload(*this, mem.data(), mem.size());
+                    }
                 }
             }
             xcap = rcap = (size_t)d.n;
@@ -1502,6 +1515,20 @@ void Engine::op_residual_restrict(int l, const double *b, const double *x, doubl
     launch_resid_pair(lev_[l].A, a, lev_[l].fine, st_, cfg_);
 }
 
+void Engine::op_jacobi_prolong(int l, const double *b, const double *x, double *xf)
+{
+    DevLevel &F = lev_[l - 1];
+    CsrArgs a;
+    a.x = x;
+    a.b = b;
+    a.d = lev_[l].diag;
+    a.omega = prm_.omega;
+    a.y2 = xf;
+    a.members = F.pair_aggregates ? nullptr : F.members;
+    a.nfine = F.n;
+    apply_A(lev_[l], OP_JACOBI_PROLONG, a);
+}
+
 double Engine::op_resnorm(int l, const double *b, const double *x)
 {
     CsrArgs a;
@@ -1566,7 +1593,8 @@ double Engine::op_dot(int n, const double *x, const double *y)
 
 // `sweeps` fused Jacobi sweeps on level buffers; the current iterate is L.x on entry and exit
 // (the ping-pong partner L.x2 is scratch).  parallel::jacobi_smoother, src/AMG_smoothers.cpp:53-76.
-void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, double *dot_partial, int *dot_nblk, bool zero_done)
+void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, double *dot_partial, int *dot_nblk, bool zero_done,
+                    DevLevel *prolong_to)
 {
     if (L.deep) {
         // Deep-halo leg: no exchange inside.  On entry b is valid on the layers <= K-1 and (unless x = 0) x on the
@@ -1625,6 +1653,11 @@ void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, doubl
             op = OP_JACOBI_DOT;
             a.partial = dot_partial;
             dot_done = true;
+        } else if (last && prolong_to) {  // transfer_solution rides in the epilogue: this level's iterate is dead after the leg
+            op = OP_JACOBI_PROLONG;
+            a.y2 = prolong_to->x;
+            a.members = prolong_to->pair_aggregates ? nullptr : prolong_to->members;
+            a.nfine = prolong_to->n;
         }
         const int np = apply_A(L, op, a);
         if (op == OP_JACOBI_DOT) *dot_nblk = np;
@@ -1699,10 +1732,10 @@ void Engine::vcycle(const double *b0, bool x0_zero, double *dot_partial, int *do
     op_coarse(lev_[last].b, lev_[last].x);  // Direct_Solver_Pardiso_solve
     for (int l = last; l > 0; --l) {
         DevLevel &F = lev_[l - 1];
-        op_prolong(l - 1, lev_[l].x, F.x);  // transfer_solution
+        if (!level_prolong_fused(l)) op_prolong(l - 1, lev_[l].x, F.x);  // transfer_solution (else: done by level l's last post-sweep)
         if (F.deep) deep_exchange(F, 2, F.x);  // the leg's only exchange: K ghost layers of the prolongated iterate
         const bool want_dot = (l - 1 == 0) && dot_partial;
-        smooth(F, F.b, nu, false, want_dot ? dot_partial : nullptr, dot_nblk);
+        smooth(F, F.b, nu, false, want_dot ? dot_partial : nullptr, dot_nblk, false, level_prolong_fused(l - 1) ? &lev_[l - 2] : nullptr);
     }
 }
 

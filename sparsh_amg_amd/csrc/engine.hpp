@@ -34,6 +34,8 @@ struct DevLevel {
     DevPlan planA, planP, planR;  // halo plans of A_l x, P_l x_{l+1}, R_l r_l (empty on one GPU)
     DevCsr A, P, R;
     bool P_is_aggregation = false;
+    int *members = nullptr;        // aggregates of at most two rows that are not such pairs: (first, second or -1) per coarse row, for the
+                                   // coarser level's last post-sweep to prolongate into this level itself (OP_JACOBI_PROLONG)
     bool pair_aggregates = false;  // aggregate J = fine rows (2J, 2J+1) in R's stored order: residual + restriction fuse (OP_RESID_PAIR)
     double *diag = nullptr;
     double *x = nullptr, *x2 = nullptr;  // ping-pong solution buffers (Jacobi reads old, writes new)
@@ -102,6 +104,13 @@ public:
     const KernelConfig &kernel_cfg() const { return cfg_; }
     // a captured hipGraph of the iteration replays the kernels of the configuration it was captured under: drop it
     void config_changed() { drop_graph(); }
+    // whether level l's last post-sweep also prolongates into level l - 1 (OP_JACOBI_PROLONG)
+    bool level_prolong_fused(int l) const
+    {
+        if (l < 1 || l + 1 >= (int)lev_.size() || dist_ || !cfg_.fuse_prolong || prm_.sweeps < 1 || prm_.precond_fp32) return false;
+        const DevLevel &F = lev_[l - 1];
+        return F.P_is_aggregation && !F.deep && (F.pair_aggregates || F.members) && F.R.nrow == lev_[l].n;
+    }
     // whether level l's residual, restriction and the next level's zero-guess sweep run as one launch (OP_RESID_PAIR)
     bool level_paired(int l) const
     {
@@ -182,6 +191,8 @@ public:
     bool op_restrict(int l, const double *r, double *bc, bool fuse_zero = false);
     // level_paired(l) levels: b_{l+1} = R (b - A x) and x_{l+1} = omega b_{l+1} / d_{l+1} in one launch
     void op_residual_restrict(int l, const double *b, const double *x, double *bc, double *xc);
+    // level_prolong_fused(l) levels: one sweep of level l from x whose result is added to xf (level l - 1) instead of stored
+    void op_jacobi_prolong(int l, const double *b, const double *x, double *xf);
     void op_prolong(int l, const double *xc, double *xf);
     void op_coarse(const double *b, double *x);
     // z = V32(r): one application of the opt-in fp32 preconditioner (fp64 in/out); needs precond_fp32
@@ -215,7 +226,9 @@ private:
     // dot_partial: when non-null the last post-sweep also leaves partial sums of x.b there.
     void vcycle(const double *b0, bool x0_zero, double *dot_partial, int *dot_nblk, bool zero_done0 = false);
     // zero_done: the zero-guess sweep x = omega*b/d has already been written to L.x (fused into the restriction)
-    void smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, double *dot_partial, int *dot_nblk, bool zero_done = false);
+    // prolong_to: the finer level whose iterate the last sweep adds its result to (level_prolong_fused), nullptr = store it
+    void smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, double *dot_partial, int *dot_nblk, bool zero_done = false,
+                DevLevel *prolong_to = nullptr);
     bool halo(const DevPlan &p, double *vec);  // pack + exchange (no-op on one GPU)
     // deep-halo level: fill the ghost layers <= depth (which: 0 depth 1, 1 depth K-1, 2 depth K) of vec from their owners
     bool deep_exchange(DevLevel &L, int which, double *vec);

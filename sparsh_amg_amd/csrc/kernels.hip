@@ -114,9 +114,9 @@ __device__ __forceinline__ int ld_stream(const int *p)
 //  * sell_kernel (kind 2): sliced-ELL mirror, lane = row, no LDS: every load of a wave is one
 //    contiguous segment (and for stencil matrices so is the x gather).
 
-constexpr bool op_needs_b(int OP) { return OP == OP_RESID || OP == OP_JACOBI || OP == OP_JACOBI_DOT || OP == OP_RESNORM || OP == OP_RESID_PAIR; }
-constexpr bool op_needs_d(int OP) { return OP == OP_JACOBI || OP == OP_JACOBI_DOT; }
-constexpr bool op_needs_xi(int OP) { return OP == OP_JACOBI || OP == OP_JACOBI_DOT || OP == OP_SPMV_DOT; }
+constexpr bool op_needs_b(int OP) { return OP == OP_RESID || OP == OP_JACOBI || OP == OP_JACOBI_DOT || OP == OP_RESNORM || OP == OP_RESID_PAIR || OP == OP_JACOBI_PROLONG; }
+constexpr bool op_needs_d(int OP) { return OP == OP_JACOBI || OP == OP_JACOBI_DOT || OP == OP_JACOBI_PROLONG; }
+constexpr bool op_needs_xi(int OP) { return OP == OP_JACOBI || OP == OP_JACOBI_DOT || OP == OP_SPMV_DOT || OP == OP_JACOBI_PROLONG; }
 constexpr bool op_reduces(int OP) { return OP == OP_SPMV_DOT || OP == OP_RESNORM || OP == OP_JACOBI_DOT; }
 
 struct RowOperands {
@@ -149,6 +149,26 @@ __device__ __forceinline__ double row_epilogue(const CsrArgs &a, int row, double
         const double xn = o.xi + a.omega * h / o.di;
         a.y[row] = xn;
         if constexpr (OP == OP_JACOBI_DOT) return xn * o.bi;
+    } else if constexpr (OP == OP_JACOBI_PROLONG) {
+        const double h = 1.0 * o.bi + (-1.0) * sum;
+        const double xn = o.xi + a.omega * h / o.di;
+        // transfer_solution for the rows this aggregate owns: x_f = 1.0 * x_c + x_f (nobody else writes them)
+        if (a.members) {
+            const i2v m = *reinterpret_cast<const i2v *>(a.members + 2 * (size_t)row);
+            a.y2[m.x] = 1.0 * xn + a.y2[m.x];
+            if (m.y >= 0) a.y2[m.y] = 1.0 * xn + a.y2[m.y];
+        } else {
+            const int f = 2 * row;
+            if (f + 1 < a.nfine) {
+                d2v *p = reinterpret_cast<d2v *>(a.y2 + f);
+                d2v v = *p;
+                v.x = 1.0 * xn + v.x;
+                v.y = 1.0 * xn + v.y;
+                *p = v;
+            } else {
+                a.y2[f] = 1.0 * xn + a.y2[f];
+            }
+        }
     } else if constexpr (OP == OP_ADD) {
         a.y[row] = sum + a.y[row];
     } else if constexpr (OP == OP_SPMV_DOT) {
@@ -1967,6 +1987,7 @@ int launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool finest, hipStre
     case OP_SPMV_DOT: return launch_csr_op<OP_SPMV_DOT>(A, a, finest, st, cfg);
     case OP_RESNORM: return launch_csr_op<OP_RESNORM>(A, a, finest, st, cfg);
     case OP_JACOBI_DOT: return launch_csr_op<OP_JACOBI_DOT>(A, a, finest, st, cfg);
+    case OP_JACOBI_PROLONG: return launch_csr_op<OP_JACOBI_PROLONG>(A, a, finest, st, cfg);
     case OP_RESID_PAIR: break;  // table kernel only: launch_resid_pair
     }
     return 0;

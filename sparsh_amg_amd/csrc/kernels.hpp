@@ -100,6 +100,8 @@ struct KernelConfig {
     bool fuse_cg_zero = true; // PCG: the cg_update kernel also writes the V-cycle's zero-guess sweep of level 0
     int alt_dir = 1;          // consecutive sweeps of a smoothing leg walk the level in alternating directions (CsrArgs::reverse):
                               // 0 never, 1 where a sweep streams more than 640 MB (2.5x the Infinity Cache), 2 always
+    bool fuse_prolong = true;  // V-cycle: the last post-sweep of a level adds its result to the finer level's iterate itself
+                               // (OP_JACOBI_PROLONG) instead of storing it for a prolongation launch
     bool pair_restrict = true; // V-cycle: on levels whose aggregates are the row pairs (2J, 2J+1) the residual kernel also
                                // restricts and writes the coarse level's zero-guess sweep (OP_RESID_PAIR)
     int idx16 = 1;      // layout option read at setup: build the 16-bit delta column form (DevCsr::col16) for 0 no operator,
@@ -128,6 +130,9 @@ enum CsrOp : int {
     OP_SPMV_DOT = 4,  // y_i = s_i ; partial += x_i*s_i           (Ap and p.Ap of CG)
     OP_RESNORM = 5,   // partial += (s_i - b_i)^2                 (residual norm, nothing stored)
     OP_JACOBI_DOT = 6, // Jacobi sweep ; partial += y_i*b_i        (last post-sweep of PCG: z.r)
+    OP_JACOBI_PROLONG = 8, // Jacobi sweep whose result is not stored but added to the finer level's iterate: y2_f = 1.0*xn_i + y2_f
+                           // for the (at most two) fine rows f of aggregate i -- the last post-sweep of a level and
+                           // transfer_solution into the level above in one launch (aggregation P only: every fine row has one owner)
     OP_RESID_PAIR = 7  // levels whose aggregates are the row pairs (2J, 2J+1): y_J = (b - s)_2J + (b - s)_2J+1 and
                        // y2_J = omega*y_J/d_J -- residual, restriction and the coarse level's zero-guess sweep in one
                        // launch (table kernel only: launch_resid_pair)
@@ -138,7 +143,10 @@ struct CsrArgs {
     const double *b = nullptr;   // rhs (RESID/JACOBI/RESNORM)
     const double *d = nullptr;   // diagonal (JACOBI)
     double *y = nullptr;         // output
-    double *y2 = nullptr;        // second output (RESID_PAIR: the coarse level's zero-guess sweep; d is then the coarse diagonal)
+    double *y2 = nullptr;        // second output (RESID_PAIR: the coarse level's zero-guess sweep; d is then the coarse diagonal;
+                                 // JACOBI_PROLONG: the finer level's iterate)
+    const int *members = nullptr; // JACOBI_PROLONG: two fine rows per row (second -1 for a single); nullptr = rows (2i, 2i+1)
+    int nfine = 0;                // JACOBI_PROLONG: rows of the finer level
     double omega = 0.0;
     double *partial = nullptr;   // per-block partial sums (reductions), size >= nblk
     // optional subset launch of the sliced kernels (multi-GPU overlap): process only the slices

@@ -700,3 +700,45 @@ def test_paired_restriction_bitwise(name, gen):
     with pytest.raises(Exception):
         A.op_residual_restrict(0, b, b)
     A.close()
+
+
+@pytest.mark.parametrize("name,gen", [
+    ("p3d_30", lambda: problems.poisson3d(30)),          # level 0 pairs (2J, 2J+1), level 1 pairs rows one grid line apart
+    ("p2d_150", lambda: problems.poisson2d(150)),
+    ("line_40001", lambda: _line1d(40001)),              # a single-row aggregate at the end
+    ("ragged", lambda: problems.random_spd(20000, 9, seed=11)),   # CSR-stream family, members from the matching
+    ("fem", lambda: problems.fem_unstructured(60000, seed=5)),
+])
+def test_fused_prolongation_bitwise(name, gen):
+    """The last post-sweep of a level adds its result to the finer level's iterate itself (OP_JACOBI_PROLONG) where the
+    aggregates hold one or two rows.  Against the oracle's sweep + transfer_solution, bit for bit, on every such level and in
+    every kernel family the level runs; whole solves with the fusion on and off: same histories and solutions, bit for bit."""
+    rp, ci, v = gen()
+    n = len(rp) - 1
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET, max_iter=40))
+    O = oracle.Csr(rp, ci, v)
+    H = oracle.Hierarchy(O)
+    rng = np.random.default_rng(78)
+    fused = [l for l in range(A.nlevels) if A.level_prolong_fused(l)]
+    assert fused == list(range(1, A.nlevels - 1)), (name, fused, A.nlevels)  # pairwise matching: every level between the ends
+    for l in fused:
+        nl, nf = A.level_info(l)["nrow"], A.level_info(l - 1)["nrow"]
+        x, b, xf = rng.standard_normal(nl), rng.standard_normal(nl), rng.standard_normal(nf)
+        want = oracle.transfer_solution(H.P(l - 1), oracle.jacobi(H.A(l), b, x, 0), xf)
+        assert np.array_equal(A.op_jacobi_prolong(l, b, x, xf), want), (name, l)
+    b = rng.standard_normal(n)
+    out = {}
+    for on in (True, False):
+        A.set_fused_prolongation(on)
+        assert bool(A.level_prolong_fused(1)) == on
+        for method in ("amg", "pcg", "pbicg"):
+            x = np.zeros(n)
+            h, rc = A.solve(method, b, x)
+            assert rc in (0, sa.SPARSH_ENOCONV) and len(h) > 0
+            out[(on, method)] = (np.array(h), x)
+    for method in ("amg", "pcg", "pbicg"):
+        assert np.array_equal(out[(True, method)][0], out[(False, method)][0]), (name, method)
+        assert np.array_equal(out[(True, method)][1], out[(False, method)][1]), (name, method)
+    with pytest.raises(Exception):
+        A.op_jacobi_prolong(1, b, b, b)
+    A.close()

@@ -1,6 +1,7 @@
-"""Same-process A/B of the fused residual + restriction launch (sparsh_set_paired_restriction) inside the PCG iteration.
+"""Same-process A/B of the fused residual + restriction launch (sparsh_set_paired_restriction) or of the fused last post-sweep
++ prolongation (sparsh_set_fused_prolongation) inside the PCG iteration.
 
-    python tools/pair_restrict_ab.py [--n 216] [--dim 3] [--iters 96] [--reps 3] [--out FILE]
+    python tools/pair_restrict_ab.py [--what pair|prolong] [--n 216] [--dim 3] [--iters 96] [--reps 3] [--out FILE]
 
 One handle, one hierarchy; the setting is toggled between timed runs of `iters` PCG iterations (restart every 48, as bench.py
 does), alternating on / off so that drift of the box hits both sides alike.  Prints it/s per run and the median of each side.
@@ -25,13 +26,19 @@ def main():
     ap.add_argument("--iters", type=int, default=96)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--what", default="pair", choices=["pair", "prolong"])
     args = ap.parse_args()
     rp, ci, v = problems.poisson3d(args.n) if args.dim == 3 else problems.poisson2d(args.n)
     n = len(rp) - 1
     prm = sa.default_params(print_setup=0, print_solve=0, tol=0.0, check_every=1 << 30)
     A = sa.sp_matrix_mg(rp, ci, v).setup(prm)
-    paired = [l for l in range(A.nlevels - 1) if A.level_paired(l)]
-    print(f"# {args.dim}D n={args.n}: {n} rows, {A.nlevels} levels, paired levels {paired}", flush=True)
+    if args.what == "pair":
+        paired = [l for l in range(A.nlevels - 1) if A.level_paired(l)]
+        toggle = A.set_paired_restriction
+    else:
+        paired = [l for l in range(A.nlevels) if A.level_prolong_fused(l)]
+        toggle = A.set_fused_prolongation
+    print(f"# {args.dim}D n={args.n}: {n} rows, {A.nlevels} levels, {args.what}: fused levels {paired}", flush=True)
     bd, xd = A.dev_alloc(8 * n), A.dev_alloc(8 * n)
     A.h2d(bd, np.ones(n))
 
@@ -49,26 +56,26 @@ def main():
     rates = {True: [], False: []}
     hist = {}
     for on in (True, False):
-        A.set_paired_restriction(on)
+        toggle(on)
         run(48)
         hist[on] = np.array(A.krylov_history())
     assert np.array_equal(hist[True], hist[False]), "histories differ between the fused and the separate launches"
     for rep in range(args.reps):
         for on in (True, False):
-            A.set_paired_restriction(on)
+            toggle(on)
             run(48)  # warm-up under this setting
             t0 = time.perf_counter()
             run(args.iters)
             dt = time.perf_counter() - t0
             # every 48-iteration segment carries one restart (about one more iteration of work): both sides alike
             rates[on].append(args.iters / dt)
-            print(f"rep {rep} paired={int(on)}: {args.iters / dt:8.1f} it/s", flush=True)
-    rec = {"problem": f"poisson{args.dim}d n={args.n}", "rows": n, "levels": A.nlevels, "paired_levels": paired,
-           "iters_per_run": args.iters, "it_per_s_paired": [round(r, 1) for r in rates[True]],
+            print(f"rep {rep} fused={int(on)}: {args.iters / dt:8.1f} it/s", flush=True)
+    rec = {"problem": f"poisson{args.dim}d n={args.n}", "rows": n, "levels": A.nlevels, "what": args.what, "fused_levels": paired,
+           "iters_per_run": args.iters, "it_per_s_fused": [round(r, 1) for r in rates[True]],
            "it_per_s_separate": [round(r, 1) for r in rates[False]],
-           "median_paired": round(float(np.median(rates[True])), 1), "median_separate": round(float(np.median(rates[False])), 1),
+           "median_fused": round(float(np.median(rates[True])), 1), "median_separate": round(float(np.median(rates[False])), 1),
            "histories_bitwise_equal": True}
-    rec["gain"] = round(rec["median_paired"] / rec["median_separate"] - 1.0, 4)
+    rec["gain"] = round(rec["median_fused"] / rec["median_separate"] - 1.0, 4)
     print(json.dumps(rec), flush=True)
     if args.out:
         with open(args.out, "a") as f:
