@@ -296,14 +296,15 @@ def main():
         level 0 the Krylov step: SpMV with the p.Ap dot, cg_update (p, Ap, x, r, d read; x, r, z written), p update."""
         total = 0
         prev_paired = False
+        dvec = [0 if H.level_constant_diagonal(l)[0] else 8 for l in range(len(levels))]  # bytes per row of a level's diag[] stream where it is read
         for l, (nl, nnzl, pn, pnnz) in enumerate(levels[:-1]):
             ncl = levels[l + 1][0]
             total += (2 * sweeps - 1) * layout_bytes(H, nl, nnzl, l, 3)
             if l > 0 and not prev_paired:
-                total += 24 * nl
+                total += (16 + dvec[l]) * nl
             prev_paired = H.level_paired(l)
             if prev_paired:  # residual + restriction + the coarse zero-guess sweep in one launch: x, b in; b_c, x_c out, d_c in
-                total += layout_bytes(H, nl, nnzl, l, 2) + 24 * ncl
+                total += layout_bytes(H, nl, nnzl, l, 2) + (16 + dvec[l + 1]) * ncl
             else:
                 total += layout_bytes(H, nl, nnzl, l, 3) + (4 * (ncl + 1) + 4 * pnnz + 8 * nl + 8 * ncl)
             form = H.level_prolong_fused(l + 1)
@@ -314,7 +315,7 @@ def main():
                 total += 4 * nl + 8 * ncl + 16 * nl
         total += coarse["bytes"] + 16 * levels[-1][0]
         n0, nnz0 = levels[0][0], levels[0][1]
-        total += layout_bytes(H, n0, nnz0, 0, 2) + 64 * n0 + 24 * n0
+        total += layout_bytes(H, n0, nnz0, 0, 2) + (56 + dvec[0]) * n0 + 24 * n0
         return total
 
     def kernel_label(H):

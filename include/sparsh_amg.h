@@ -177,6 +177,13 @@ int sparsh_set_paired_restriction(sparsh_handle h, int enable);
  * sparsh_level_prolong_fused: whether level `level`'s last post-sweep prolongates into level - 1 itself: 0 no, 1 yes with
  * the aggregates being the row pairs (2J, 2J+1) (no index read), 2 yes through an 8-byte (first, second) record per aggregate. */
 int sparsh_set_fused_prolongation(sparsh_handle h, int enable);
+/* Levels whose diagonal is one constant (constant-coefficient stencils and their Galerkin products): the kernels that only
+ * divide by d_i -- the zero-guess sweeps x = omega b / d (parallel::jacobi_smoother's first pass, src/AMG_smoothers.cpp:53-76)
+ * fused into the PCG update and into the restriction -- take the constant as an argument instead of streaming diag[]
+ * (8 of 64 bytes per row of the PCG update).  Same division, same bits.  enable: 1 (default) / 0 (A/B).
+ * sparsh_level_constant_diagonal: whether a level of the built hierarchy qualifies under the current configuration, and the value. */
+int sparsh_set_constant_diagonal(sparsh_handle h, int enable);
+int sparsh_level_constant_diagonal(sparsh_handle h, int level, int *is_const, double *value);
 int sparsh_level_prolong_fused(sparsh_handle h, int level, int *fused);
 int sparsh_level_paired(sparsh_handle h, int level, int *paired);
 /* PCG: the x / r update kernel also writes the zero-guess sweep z0 = omega r / d of the V-cycle that follows (same bits, one

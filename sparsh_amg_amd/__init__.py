@@ -93,6 +93,8 @@ def _load():
         "sparsh_set_alternate_sweeps": (C.c_int, [H, C.c_int]),
         "sparsh_set_paired_restriction": (C.c_int, [H, C.c_int]),
         "sparsh_set_fused_prolongation": (C.c_int, [H, C.c_int]),
+        "sparsh_set_constant_diagonal": (C.c_int, [H, C.c_int]),
+        "sparsh_level_constant_diagonal": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
         "sparsh_level_prolong_fused": (C.c_int, [H, C.c_int, C.POINTER(C.c_int)]),
         "sparsh_op_jacobi_prolong": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p]),
         "sparsh_level_paired": (C.c_int, [H, C.c_int, C.POINTER(C.c_int)]),
@@ -332,6 +334,17 @@ class sp_matrix_mg:
         """Alternate the walking direction of consecutive sweeps of a smoothing leg: 0 never, 1 large streaming levels (default), 2 always."""
         _check(lib.sparsh_set_alternate_sweeps(self._h, int(mode)))
         return self
+
+    def set_constant_diagonal(self, enable=True):
+        """Levels with one constant diagonal: the zero-guess sweeps take it as an argument instead of streaming diag[]."""
+        _check(lib.sparsh_set_constant_diagonal(self._h, 1 if enable else 0))
+        return self
+
+    def level_constant_diagonal(self, level):
+        """(qualifies under the current configuration, the level's first diagonal entry)."""
+        f, v = C.c_int(0), C.c_double(0.0)
+        _check(lib.sparsh_level_constant_diagonal(self._h, int(level), C.byref(f), C.byref(v)))
+        return bool(f.value), v.value
 
     def set_fused_prolongation(self, enable=True):
         """The last post-sweep of a level adds its result to the finer level's iterate itself (aggregates of one or two rows)."""

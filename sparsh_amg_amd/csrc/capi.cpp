@@ -410,6 +410,24 @@ int sparsh_set_alternate_sweeps(sparsh_handle h, int enable)
     return SPARSH_OK;
 }
 
+int sparsh_set_constant_diagonal(sparsh_handle h, int enable)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    h->eng->kernel_cfg().const_diag = enable != 0;
+    h->eng->config_changed();
+    return SPARSH_OK;
+}
+
+int sparsh_level_constant_diagonal(sparsh_handle h, int level, int *is_const, double *value)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    const DevLevel &L = h->eng->level(level);
+    if (is_const) *is_const = h->eng->diag_stream(L) == nullptr ? 1 : 0;
+    if (value) *value = L.diag_const;
+    return SPARSH_OK;
+}
+
 int sparsh_set_fused_prolongation(sparsh_handle h, int enable)
 {
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");

@@ -1095,6 +1095,9 @@ int Engine::setup(const sparsh_params &p)
             d.n = h.A.nrow;
             if (!upload_csr(*this, h.A, d.A, true)) return SPARSH_ENODEV;
             d.diag = upload(*this, h.diag.data(), (size_t)d.n);
+            d.diag_is_const = d.n > 0;
+            for (int i = 1; i < d.n && d.diag_is_const; ++i) d.diag_is_const = h.diag[i] == h.diag[0];
+            if (d.diag_is_const) d.diag_const = h.diag[0];
             if (l + 1 < nl) {
                 if (!upload_csr(*this, h.P, d.P, false) || !upload_csr(*this, h.R, d.R, false)) return SPARSH_ENODEV;
                 d.P_is_aggregation = h.P_is_aggregation;
@@ -1510,7 +1513,8 @@ void Engine::op_residual_restrict(int l, const double *b, const double *x, doubl
     a.b = b;
     a.y = bc;
     a.y2 = xc;
-    a.d = lev_[l + 1].diag;
+    a.d = diag_stream(lev_[l + 1]);
+    a.dconst = lev_[l + 1].diag_const;
     a.omega = prm_.omega;
     launch_resid_pair(lev_[l].A, a, lev_[l].fine, st_, cfg_);
 }
@@ -1551,7 +1555,7 @@ bool Engine::op_restrict(int l, const double *r, double *bc, bool fuse_zero)
     bool fused = false;
     if (L.P_is_aggregation && fuse_zero && !gather && l + 2 < (int)lev_.size() && lev_[l + 1].n == L.R.nrow) {
         // the coarse level's first pre-sweep from a zero guess rides along (one launch less per level)
-        launch_restrict_agg_zero(L.R.nrow, L.R.rowptr, L.R.col, r, a.y, lev_[l + 1].diag, prm_.omega, lev_[l + 1].x, st_);
+        launch_restrict_agg_zero(L.R.nrow, L.R.rowptr, L.R.col, r, a.y, diag_stream(lev_[l + 1]), lev_[l + 1].diag_const, prm_.omega, lev_[l + 1].x, st_);
         fused = true;
     } else if (L.P_is_aggregation) {
         launch_restrict_agg(L.R.nrow, L.R.rowptr, L.R.col, r, a.y, st_);
@@ -1605,7 +1609,7 @@ void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, doubl
         const bool timed = prof.enabled && &L == &lev_[0] && prof.used + 2 <= prof.ev.size();
         int in_run = 0;
         if (x_zero && sweeps > 0) {
-            if (!zero_done) launch_jacobi_zero(L.layer_end[K - 1], b, L.diag, prm_.omega, L.x, st_);
+            if (!zero_done) launch_jacobi_zero(L.layer_end[K - 1], b, L.diag, 0.0, prm_.omega, L.x, st_);
             s = 1;
         }
         if (timed) HIPCHK(hipEventRecord(prof.ev[prof.used], st_));
@@ -1633,7 +1637,7 @@ void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, doubl
     int k = 0;
     bool dot_done = false;
     if (x_zero && sweeps > 0) {
-        if (!zero_done) launch_jacobi_zero(L.n, b, L.diag, prm_.omega, L.x, st_);
+        if (!zero_done) launch_jacobi_zero(L.n, b, diag_stream(L), L.diag_const, prm_.omega, L.x, st_);
         k = 1;
     }
     const bool timed = prof.enabled && &L == &lev_[0] && k < sweeps && prof.used + 2 <= prof.ev.size();
@@ -1840,7 +1844,7 @@ void Engine::pcg_body(bool precond, int slot)
     // with the fp64 V-cycle behind it the update also writes the cycle's zero-guess sweep of level 0 (z0 = omega r / d)
     const bool fuse_zero = cfg_.fuse_cg_zero && precond && !f32_ready_ && lev_.size() > 1 && !lev_[0].deep && prm_.sweeps > 0;
     if (fuse_zero)
-        launch_cg_update_zero(n, scal_, p, Ap, x, r, part1_, &nb, lev_[0].diag, prm_.omega, lev_[0].x, st_, cfg_.cg_nt);
+        launch_cg_update_zero(n, scal_, p, Ap, x, r, part1_, &nb, diag_stream(lev_[0]), lev_[0].diag_const, prm_.omega, lev_[0].x, st_, cfg_.cg_nt);
     else
         launch_cg_update(n, scal_, p, Ap, x, r, precond ? part1_ : part0_, &nb, st_);
     if (precond && f32_ready_) {

@@ -38,6 +38,8 @@ struct DevLevel {
                                    // coarser level's last post-sweep to prolongate into this level itself (OP_JACOBI_PROLONG)
     bool pair_aggregates = false;  // aggregate J = fine rows (2J, 2J+1) in R's stored order: residual + restriction fuse (OP_RESID_PAIR)
     double *diag = nullptr;
+    bool diag_is_const = false;  // every (own) row has the same diagonal entry, diag_const
+    double diag_const = 0.0;
     double *x = nullptr, *x2 = nullptr;  // ping-pong solution buffers (Jacobi reads old, writes new)
     double *b = nullptr;                 // rhs of this level (level 0: points at the caller's vector)
     double *r = nullptr;                 // residual
@@ -104,6 +106,8 @@ public:
     const KernelConfig &kernel_cfg() const { return cfg_; }
     // a captured hipGraph of the iteration replays the kernels of the configuration it was captured under: drop it
     void config_changed() { drop_graph(); }
+    // diag[] of a level for the kernels that only divide by it: nullptr (+ diag_const) where it is one constant
+    const double *diag_stream(const DevLevel &L) const { return cfg_.const_diag && L.diag_is_const ? nullptr : L.diag; }
     // whether level l's last post-sweep also prolongates into level l - 1 (OP_JACOBI_PROLONG)
     bool level_prolong_fused(int l) const
     {

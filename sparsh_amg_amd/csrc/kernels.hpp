@@ -100,6 +100,8 @@ struct KernelConfig {
     bool fuse_cg_zero = true; // PCG: the cg_update kernel also writes the V-cycle's zero-guess sweep of level 0
     int alt_dir = 1;          // consecutive sweeps of a smoothing leg walk the level in alternating directions (CsrArgs::reverse):
                               // 0 never, 1 where a sweep streams more than 640 MB (2.5x the Infinity Cache), 2 always
+    bool const_diag = true;    // levels whose diagonal is one constant: the vector kernels that divide by it (zero-guess sweeps fused
+                               // into cg_update / the restriction) take it as an argument instead of streaming diag[]
     bool fuse_prolong = true;  // V-cycle: the last post-sweep of a level adds its result to the finer level's iterate itself
                                // (OP_JACOBI_PROLONG) instead of storing it for a prolongation launch
     bool pair_restrict = true; // V-cycle: on levels whose aggregates are the row pairs (2J, 2J+1) the residual kernel also
@@ -145,6 +147,7 @@ struct CsrArgs {
     double *y = nullptr;         // output
     double *y2 = nullptr;        // second output (RESID_PAIR: the coarse level's zero-guess sweep; d is then the coarse diagonal;
                                  // JACOBI_PROLONG: the finer level's iterate)
+    double dconst = 0.0;         // RESID_PAIR with d == nullptr: the coarse level's constant diagonal
     const int *members = nullptr; // JACOBI_PROLONG: two fine rows per row (second -1 for a single); nullptr = rows (2i, 2i+1)
     int nfine = 0;                // JACOBI_PROLONG: rows of the finer level
     double omega = 0.0;
@@ -184,14 +187,15 @@ int sdia_tile_rows(const DevCsr &A, const KernelConfig &cfg);  // rows per workg
 void csr_placement(const DevCsr &A, const KernelConfig &cfg, bool *nt, int *remap);
 
 // x_i = omega*b_i/d_i : first Jacobi sweep from a zero guess (bitwise equal to the full sweep)
-void launch_jacobi_zero(int n, const double *b, const double *d, double omega, double *x, hipStream_t st);
+// (here and below: d == nullptr means every row's diagonal entry is dconst -- constant-coefficient stencils: the stream is not read)
+void launch_jacobi_zero(int n, const double *b, const double *d, double dconst, double omega, double *x, hipStream_t st);
 // xf_i = xc[agg_i] + xf_i : prolongation for an aggregation P (one unit entry per row)
 void launch_prolong_agg(int n, const int *agg, const double *xc, double *xf, hipStream_t st);
 // bc[J] = sum of r over aggregate J (R = P^T of an aggregation P: all values 1.0, not read)
 void launch_restrict_agg(int nc, const int *rowptr, const int *col, const double *r, double *bc, hipStream_t st);
 // the same, and xc[J] = omega*bc[J]/dc[J]: the coarse level's zero-guess sweep in the same launch
-void launch_restrict_agg_zero(int nc, const int *rowptr, const int *col, const double *r, double *bc, const double *dc, double omega,
-                              double *xc, hipStream_t st);
+void launch_restrict_agg_zero(int nc, const int *rowptr, const int *col, const double *r, double *bc, const double *dc, double dconst,
+                              double omega, double *xc, hipStream_t st);
 // x = A^{-1} b with the explicit row-major inverse (coarsest level)
 void launch_gemv(int n, const double *M, const double *b, double *x, hipStream_t st);
 
@@ -265,7 +269,7 @@ void launch_cg_update(int n, const double *scal, const double *p, const double *
                       int *nblk, hipStream_t st);
 // the same, and z0 = omega * r / d on the new residual: the zero-guess sweep of the V-cycle that follows (PCG)
 void launch_cg_update_zero(int n, const double *scal, const double *p, const double *Ap, double *x, double *r, double *partial,
-                           int *nblk, const double *d, double omega, double *z0, hipStream_t st, bool nt = false);
+                           int *nblk, const double *d, double dconst, double omega, double *z0, hipStream_t st, bool nt = false);
 // p = 1.0*z + beta*p
 void launch_p_update(int n, const double *scal, const double *z, double *p, hipStream_t st);
 // two dots at once: partial0 += a.b, partial1 += c.d

@@ -742,3 +742,31 @@ def test_fused_prolongation_bitwise(name, gen):
     with pytest.raises(Exception):
         A.op_jacobi_prolong(1, b, b, b)
     A.close()
+
+
+def test_constant_diagonal_levels_bitwise():
+    """Levels whose diagonal is one constant hand it to the zero-guess sweeps as an argument (no diag[] stream): same bits as
+    with the stream, for the V-cycle alone and inside PCG; an operator with varying diagonal does not qualify."""
+    rp, ci, v = problems.poisson3d(30)
+    n = len(rp) - 1
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET))
+    flags = [A.level_constant_diagonal(l) for l in range(A.nlevels)]
+    assert flags[0] == (True, 6.0) and flags[1][0], flags
+    b = np.random.default_rng(79).standard_normal(n)
+    out = {}
+    for on in (True, False):
+        A.set_constant_diagonal(on)
+        assert A.level_constant_diagonal(0)[0] == on
+        for method in ("amg", "pcg"):
+            x = np.zeros(n)
+            h, rc = A.solve(method, b, x)
+            assert rc == 0
+            out[(on, method)] = (np.array(h), x)
+    for method in ("amg", "pcg"):
+        assert np.array_equal(out[(True, method)][0], out[(False, method)][0])
+        assert np.array_equal(out[(True, method)][1], out[(False, method)][1])
+    A.close()
+    rp, ci, v = problems.random_spd(20000, 9, seed=11)
+    B = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET))
+    assert not B.level_constant_diagonal(0)[0]
+    B.close()
