@@ -183,6 +183,19 @@ int sparsh_set_fused_prolongation(sparsh_handle h, int enable);
  * (8 of 64 bytes per row of the PCG update).  Same division, same bits.  enable: 1 (default) / 0 (A/B).
  * sparsh_level_constant_diagonal: whether a level of the built hierarchy qualifies under the current configuration, and the value. */
 int sparsh_set_constant_diagonal(sparsh_handle h, int enable);
+/* Double sweep.  A level whose operator is the 7-point stencil of an nx x ny x nz box grid in lexicographic order (constant
+ * coefficients; the finest levels of BASELINE configs[1]'s 3D cases and their Galerkin products) can run two sweeps of
+ * parallel::jacobi_smoother (src/AMG_smoothers.cpp:53-76) in one pass over x, b and the result: a workgroup marches through
+ * the planes of its tile with the first sweep's plane in LDS, so that sweep's result is never written (temporal blocking;
+ * ~30 instead of 48 bytes per row and pair of sweeps).  Every row is computed with the same products in the same order:
+ * results are bitwise those of two single sweeps.  mode, read by sparsh_setup: 0 never; 1 (default) on levels of >= 400 000 rows
+ * where the setup times it faster than two single sweeps; 2 on every box-grid level that has a launch plan (tests, A/B).
+ * After setup the mode may be switched between 0 and its setup value.
+ * sparsh_level_double_sweep: on = the level's smoothing legs use it; dims = {nx, ny, nz} (0: not a box grid); plan = {points per
+ * thread, lines per tile, planes per chunk}; the setup's timings of two single sweeps / one double sweep in us (0: not timed).
+ * Any output pointer may be NULL. */
+int sparsh_set_double_sweep(sparsh_handle h, int mode);
+int sparsh_level_double_sweep(sparsh_handle h, int level, int *on, int *dims, int *plan, double *single_us, double *double_us);
 int sparsh_level_constant_diagonal(sparsh_handle h, int level, int *is_const, double *value);
 int sparsh_level_prolong_fused(sparsh_handle h, int level, int *fused);
 int sparsh_level_paired(sparsh_handle h, int level, int *paired);

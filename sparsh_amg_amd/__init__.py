@@ -94,6 +94,9 @@ def _load():
         "sparsh_set_paired_restriction": (C.c_int, [H, C.c_int]),
         "sparsh_set_fused_prolongation": (C.c_int, [H, C.c_int]),
         "sparsh_set_constant_diagonal": (C.c_int, [H, C.c_int]),
+        "sparsh_set_double_sweep": (C.c_int, [H, C.c_int]),
+        "sparsh_level_double_sweep": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                                  C.POINTER(C.c_double)]),
         "sparsh_level_constant_diagonal": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
         "sparsh_level_prolong_fused": (C.c_int, [H, C.c_int, C.POINTER(C.c_int)]),
         "sparsh_op_jacobi_prolong": (C.c_int, [H, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p]),
@@ -334,6 +337,20 @@ class sp_matrix_mg:
         """Alternate the walking direction of consecutive sweeps of a smoothing leg: 0 never, 1 large streaming levels (default), 2 always."""
         _check(lib.sparsh_set_alternate_sweeps(self._h, int(mode)))
         return self
+
+    def set_double_sweep(self, mode=1):
+        """Two Jacobi sweeps per launch on box-grid levels: 0 never, 1 where the setup times it faster (default), 2 wherever a plan exists.
+        Read by setup; afterwards it can be switched between 0 and the setup's value."""
+        _check(lib.sparsh_set_double_sweep(self._h, int(mode)))
+        return self
+
+    def level_double_sweep(self, level):
+        on = C.c_int(0)
+        dims, plan = (C.c_int * 3)(), (C.c_int * 3)()
+        t1, t2 = C.c_double(0.0), C.c_double(0.0)
+        _check(lib.sparsh_level_double_sweep(self._h, int(level), C.byref(on), dims, plan, C.byref(t1), C.byref(t2)))
+        return {"on": bool(on.value), "grid": list(dims), "points_per_thread": plan[0], "lines_per_tile": plan[1], "planes_per_chunk": plan[2],
+                "two_single_sweeps_us": round(t1.value, 2), "double_sweep_us": round(t2.value, 2)}
 
     def set_constant_diagonal(self, enable=True):
         """Levels with one constant diagonal: the zero-guess sweeps take it as an argument instead of streaming diag[]."""

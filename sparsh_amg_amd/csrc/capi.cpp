@@ -410,6 +410,36 @@ int sparsh_set_alternate_sweeps(sparsh_handle h, int enable)
     return SPARSH_OK;
 }
 
+int sparsh_set_double_sweep(sparsh_handle h, int mode)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    if (mode < 0 || mode > 2) return fail(SPARSH_EINVAL, "mode must be 0 (never), 1 (where the setup measures it faster) or 2 (wherever the level is a box grid with a plan)");
+    h->eng->kernel_cfg().box2 = mode;
+    h->eng->config_changed();
+    return SPARSH_OK;
+}
+
+int sparsh_level_double_sweep(sparsh_handle h, int level, int *on, int *dims, int *plan, double *single_us, double *double_us)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    const DevLevel &L = h->eng->level(level);
+    if (on) *on = !h->eng->distributed() && box2_applies(L.A, h->eng->kernel_cfg()) ? 1 : 0;
+    if (dims) {
+        dims[0] = L.A.box_nx;
+        dims[1] = L.A.box_ny;
+        dims[2] = L.A.box_nz;
+    }
+    if (plan) {
+        plan[0] = L.A.box_q;
+        plan[1] = L.A.box_ty;
+        plan[2] = L.A.box_cz;
+    }
+    if (single_us) *single_us = L.box_single_us;
+    if (double_us) *double_us = L.box_double_us;
+    return SPARSH_OK;
+}
+
 int sparsh_set_constant_diagonal(sparsh_handle h, int enable)
 {
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");

@@ -363,6 +363,30 @@ bool upload_sdia(Engine &E, const HostCsr &A, DevCsr &D)
                 D.sd_tconf = upload(E, tconf.data(), tconf.size());
                 if (!D.sd_tmask || !D.sd_tconf) return false;
             }
+            // box grid (DevCsr::box_nx): 7-point table (-P, -L, -1, 0, +1, +L, +P), every slice on it, and every row lacking
+            // exactly the neighbours outside an L x P/L x n/P box
+            if (nconf == (long)nslice && !local && tab.near == 73 && A.ncol == n && tab.off[5] >= 2 && tab.off[1] == -tab.off[5] && tab.off[6] > tab.off[5] &&
+                tab.off[0] == -tab.off[6] && tab.off[6] % tab.off[5] == 0 && n % tab.off[6] == 0) {
+                const int nx = tab.off[5], P = tab.off[6], ny = P / nx, nz = n / P;
+                long bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+                for (int sl = 0; sl < nslice; ++sl) {
+                    const unsigned long long *mm = &tmask[(size_t)sl * 8];
+                    const int r1 = std::min(n, (sl + 1) * 64);
+                    for (int r = sl * 64; r < r1; ++r) {
+                        const int k = r / P, rem = r - k * P, j = rem / nx, i = rem - j * nx;
+                        const bool want[7] = {k > 0, j > 0, i > 0, true, i < nx - 1, j < ny - 1, k < nz - 1};
+                        for (int u = 0; u < 7; ++u)
+                            if ((((mm[u] >> (r & 63)) & 1ull) != 0) != want[u]) ++bad;
+                    }
+                }
+                if (bad == 0) {
+                    D.box_nx = nx;
+                    D.box_ny = ny;
+                    D.box_nz = nz;
+                    box2_plan(D);
+                }
+            }
         }
     }
     D.sd_ptr = upload(E, sp.data(), sp.size());
@@ -612,6 +636,55 @@ int Engine::setup_host_shared(const sparsh_params &p)
 // process to the next (profiles/r02_finest_sweep_placement_luck.txt).  The engine owns eleven buffers of that size anyway
 // (x, x2, r of level 0 and the Krylov vectors), so it times the sweep on the candidate triples once and lets the best one
 // play the three roles -- an assignment of pointers, no extra memory, results unchanged.
+// Box-grid levels: does the double sweep (sdia_box2_kernel) beat two single sweeps here?  Timed on the level's own buffers
+// (KernelConfig::box2 = 1, levels of >= 400 000 rows: below that two launches of a cache-resident level win, tools/micro/box2_proto)
+// or switched on wherever a plan exists (box2 = 2: tests, A/B).
+void Engine::tune_box2()
+{
+    for (size_t l = 0; l + 1 < lev_.size(); ++l) {
+        DevLevel &L = lev_[l];
+        L.A.box_on = false;
+        L.box_single_us = L.box_double_us = 0.0;
+        if (cfg_.box2 == 0 || L.A.box_q <= 0 || dist_ || L.deep || csr_family(L.A, cfg_) != FAM_SDIA_TAB) continue;
+        if (cfg_.box2 >= 2) {
+            L.A.box_on = true;
+            continue;
+        }
+        if (L.n < 400000) continue;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) continue;
+        CsrArgs a;
+        a.b = L.r;  // (scratch: any vector of the level's length)
+        a.d = L.diag;
+        a.omega = prm_.omega;
+        auto timed = [&](bool fused) -> double {
+            double *p = L.x, *q = L.x2;
+            const int launches = fused ? 5 : 10;
+            for (int it = 0; it < launches; ++it) {
+                if (it == (fused ? 1 : 2)) (void)hipEventRecord(e0, st_);
+                if (fused) {
+                    launch_box2(L.A, p, a.b, q, prm_.omega, L.fine, st_);
+                } else {
+                    a.x = p;
+                    a.y = q;
+                    launch_csr(L.A, OP_JACOBI, a, L.fine, st_, cfg_);
+                }
+                std::swap(p, q);
+            }
+            (void)hipEventRecord(e1, st_);
+            if (hipEventSynchronize(e1) != hipSuccess) return 1e30;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            return (double)ms * 1e3 / 4.0;  // per pair of sweeps
+        };
+        L.box_single_us = timed(false);
+        L.box_double_us = timed(true);
+        L.A.box_on = L.box_double_us < 0.97 * L.box_single_us;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+}
+
 void Engine::tune_placement()
 {
     if (lev_.size() < 2) return;
@@ -644,11 +717,16 @@ void Engine::tune_placement()
         a.d = L.diag;
         a.omega = prm_.omega;
         double *p = x, *q = x2;
-        for (int it = 0; it < 10; ++it) {
-            if (it == 2) (void)hipEventRecord(e0, st_);
-            a.x = p;
-            a.y = q;
-            launch_csr(L.A, OP_JACOBI, a, L.fine, st_, cfg_);
+        const bool pairs = box2_applies(L.A, cfg_);  // the kernel the smoothing legs will run: 5 double sweeps or 10 single ones
+        for (int it = 0; it < (pairs ? 5 : 10); ++it) {
+            if (it == (pairs ? 1 : 2)) (void)hipEventRecord(e0, st_);
+            if (pairs) {
+                launch_box2(L.A, p, b, q, prm_.omega, L.fine, st_);
+            } else {
+                a.x = p;
+                a.y = q;
+                launch_csr(L.A, OP_JACOBI, a, L.fine, st_, cfg_);
+            }
             std::swap(p, q);
         }
         (void)hipEventRecord(e1, st_);
@@ -1257,6 +1335,7 @@ int Engine::setup(const sparsh_params &p)
     place_tried = 0;
     place_best_us = place_worst_us = place_first_us = 0.0;
     phase("coarsest-level factorisation + workspace");
+    if (G == 1) tune_box2();
     if (G == 1 && cfg_.place_search) tune_placement();
     phase("placement search");
     f32_ready_ = false;
@@ -1643,8 +1722,25 @@ void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, doubl
     const bool timed = prof.enabled && &L == &lev_[0] && k < sweeps && prof.used + 2 <= prof.ev.size();
     if (timed) HIPCHK(hipEventRecord(prof.ev[prof.used], st_));
     int in_run = 0;
+    const bool pairs = !dist_ && box2_applies(L.A, cfg_);
+    bool timed_open = timed;
+    const bool special_last = dot_partial || prolong_to;  // the last sweep carries an epilogue of its own
     for (; k < sweeps; ++k) {
         const bool last = (k == sweeps - 1);
+        if (pairs && k + 2 <= sweeps - (special_last ? 1 : 0)) {  // two plain sweeps in one pass over the vectors
+            launch_box2(L.A, L.x, b, L.x2, prm_.omega, L.fine, st_);
+            ++k;
+            ++in_run;
+            std::swap(L.x, L.x2);
+            // profiling a level that runs double sweeps: the timed run is its double-sweep launches alone
+            if (timed_open && !(k + 3 <= sweeps - (special_last ? 1 : 0))) {
+                HIPCHK(hipEventRecord(prof.ev[prof.used + 1], st_));
+                prof.run_launches.push_back(in_run);
+                prof.used += 2;
+                timed_open = false;
+            }
+            continue;
+        }
         CsrArgs a;
         a.x = L.x;
         a.b = b;
@@ -1668,7 +1764,7 @@ void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, doubl
         ++in_run;
         std::swap(L.x, L.x2);
     }
-    if (timed) {
+    if (timed_open && !pairs) {
         HIPCHK(hipEventRecord(prof.ev[prof.used + 1], st_));
         prof.run_launches.push_back(in_run);
         prof.used += 2;

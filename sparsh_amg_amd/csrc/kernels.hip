@@ -1219,6 +1219,151 @@ __global__ __launch_bounds__(kTileBlock) void sdia_tile_kernel(int nrow, int xle
     }
 }
 
+// ------------------------------------------------------------------ double sweep on box grids
+// Two Jacobi sweeps in one pass over x, b and y (temporal blocking).  The single-sweep table kernel at 216^3 moves 24 B per
+// row and sweep at the rate HBM delivers (profiles/r03_pmc); the only way below that is to not write the first sweep's result.
+// A workgroup of 1024 threads owns TY grid lines of every plane of a chunk of CZ planes and marches through the planes:
+//   region in a plane = lines j0-2 .. j0+TY+1 (contiguous in memory), thread t owns the points p = t + 1024 q, q < Q;
+//   x0 of plane k sits in LDS (X0) for the in-plane neighbours, x0 of planes k-1 / k+1 at the own point in registers;
+//   step k: x1 = J(x0) on plane k, lines 1 .. TY+2 of the region (one ring more than the tile: recomputed, not exchanged --
+//           the same expression on the same operands gives the neighbour workgroup's bits);
+//           x2 = J(x1) on plane k-1, lines 2 .. TY+1, from x1 of plane k-1 in LDS (X1) and of planes k-2 / k in registers; stored.
+// Neighbours that do not exist are read as +0.0 -- a zero pad cell between the lines in LDS, zero lines and planes outside the
+// grid: c * 0.0 = +-0.0 and sum + (+-0.0) == sum bit for bit (sum is never -0.0: it starts at +0.0, and x + y = -0.0 only for
+// x = y = -0.0), which is exactly "skip the missing entry" of the table kernel, without a predicate.  Every row is computed with
+// the table kernel's products in the table kernel's order, so y is bitwise what two OP_JACOBI launches produce.
+// Reads per row and double sweep: x (TY+4)/TY * (CZ+3)/CZ, b (TY+2)/TY * (CZ+2)/CZ, one store: ~30 B instead of 48.
+constexpr int kBoxBlock = 1024;
+
+struct BoxArgs {
+    int nx, ny, nz;
+    int TY, CZ, ytiles;
+    double c[7];  // -plane, -line, -1, 0, +1, +line, +plane
+    double omega;
+};
+
+template <int Q, int TAG>
+__global__ __launch_bounds__(kBoxBlock) void sdia_box2_kernel(BoxArgs g, const double *__restrict__ x, const double *__restrict__ b,
+                                                               double *__restrict__ y)
+{
+    extern __shared__ double box_lds[];
+    const int nx = g.nx, ny = g.ny, nz = g.nz, P = nx * ny, TY = g.TY;
+    const int R0 = (TY + 4) * nx;
+    const int pitch = nx + 1;
+    const int cells = (TY + 4) * pitch + 1;
+    double *X0 = box_lds;          // x0, plane k, whole region
+    double *X1 = box_lds + cells;  // x1, plane k-1
+    // workgroups go round-robin to the 8 XCDs: every XCD gets a contiguous run of (chunk, tile) pairs, so tiles that share
+    // halo lines sit behind the same L2
+    int wg = blockIdx.x;
+    {
+        const int nwg = gridDim.x, per = nwg / 8, rem = nwg % 8;
+        const int c = wg % 8, r = wg / 8;
+        wg = c * per + min(c, rem) + r;
+    }
+    const int tile = wg % g.ytiles, zc = wg / g.ytiles;
+    const int j0 = tile * TY;
+    const int z0 = zc * g.CZ, z1 = min(z0 + g.CZ, nz);
+    const long base = (long)(j0 - 2) * nx;  // + k*P + p = global row
+    const int tid = threadIdx.x;
+    const double c0 = g.c[0], c1 = g.c[1], c2 = g.c[2], c3 = g.c[3], c4 = g.c[4], c5 = g.c[5], c6 = g.c[6], om = g.omega;
+    for (int i = tid; i < 2 * cells; i += kBoxBlock) box_lds[i] = 0.0;
+    bool v0[Q], v1[Q], v2[Q];
+    int sidx[Q];
+    double xm[Q], xc[Q], xp[Q], bk[Q], bp[Q], x1m[Q], x1c[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int p = tid + kBoxBlock * q;
+        const int lr = p / nx;
+        const int jr = j0 - 2 + lr;
+        sidx[q] = p + lr + 1;
+        v0[q] = p < R0 && jr >= 0 && jr < ny;
+        v1[q] = v0[q] && lr >= 1 && lr <= TY + 2;
+        v2[q] = v0[q] && lr >= 2 && lr <= TY + 1;
+        xm[q] = xc[q] = xp[q] = bk[q] = bp[q] = x1m[q] = x1c[q] = 0.0;
+    }
+    const int ks = z0 - 1;  // first plane of the first sweep (-1: does not exist)
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int p = tid + kBoxBlock * q;
+        if (v0[q]) {
+            if (ks >= 1) xm[q] = x[(long)(ks - 1) * P + base + p];
+            if (ks >= 0) xc[q] = x[(long)ks * P + base + p];
+            if (ks + 1 < nz) xp[q] = x[(long)(ks + 1) * P + base + p];
+        }
+        if (v1[q] && ks >= 0) bk[q] = b[(long)ks * P + base + p];
+    }
+    __syncthreads();
+    for (int k = ks; k <= z1; ++k) {  // every thread of the workgroup runs the same z1 - ks + 1 steps
+        const bool plane = k >= 0 && k < nz;  // uniform
+        double xn[Q], bn[Q];  // operands of the next step: in flight across this one
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int p = tid + kBoxBlock * q;
+            xn[q] = 0.0;
+            bn[q] = 0.0;
+            if (k + 1 <= z1) {
+                if (v0[q] && k + 2 < nz) xn[q] = x[(long)(k + 2) * P + base + p];
+                if (v1[q] && k + 1 < nz) bn[q] = b[(long)(k + 1) * P + base + p];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+            if (v0[q]) X0[sidx[q]] = xc[q];
+        __syncthreads();
+        double x1k[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            x1k[q] = 0.0;
+            if (plane && v1[q]) {
+                const int s = sidx[q];
+                double sum = 0.0;
+                sum = sum + c0 * xm[q];
+                sum = sum + c1 * X0[s - pitch];
+                sum = sum + c2 * X0[s - 1];
+                sum = sum + c3 * xc[q];
+                sum = sum + c4 * X0[s + 1];
+                sum = sum + c5 * X0[s + pitch];
+                sum = sum + c6 * xp[q];
+                const double h = 1.0 * bk[q] + (-1.0) * sum;
+                x1k[q] = xc[q] + om * h / c3;
+            }
+        }
+        const int k2 = k - 1;
+        if (k2 >= z0 && k2 < z1) {  // uniform
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int p = tid + kBoxBlock * q;
+                if (v2[q]) {
+                    const int s = sidx[q];
+                    double sum = 0.0;
+                    sum = sum + c0 * x1m[q];
+                    sum = sum + c1 * X1[s - pitch];
+                    sum = sum + c2 * X1[s - 1];
+                    sum = sum + c3 * x1c[q];
+                    sum = sum + c4 * X1[s + 1];
+                    sum = sum + c5 * X1[s + pitch];
+                    sum = sum + c6 * x1k[q];
+                    const double h = 1.0 * bp[q] + (-1.0) * sum;
+                    y[(long)k2 * P + base + p] = x1c[q] + om * h / c3;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            if (v1[q]) X1[sidx[q]] = x1k[q];
+            x1m[q] = x1c[q];
+            x1c[q] = x1k[q];
+            xm[q] = xc[q];
+            xc[q] = xp[q];
+            xp[q] = xn[q];
+            bp[q] = bk[q];
+            bk[q] = bn[q];
+        }
+    }
+}
+
 // ------------------------------------------------------------------ fp32 preconditioner kernels
 // Same sliced-diagonal structure with float values and float vectors: 4 B per stored entry and
 // 12 B per row for a fused sweep.  Used only inside the (opt-in) fp32 V-cycle; the fp64 parity
@@ -1463,6 +1608,70 @@ int launch_csr_tagged(const DevCsr &A, const CsrArgs &a, bool nt, int remap, hip
 }
 
 }  // namespace
+
+namespace {
+size_t box2_lds_bytes(int nx, int TY) { return (size_t)2 * ((size_t)(TY + 4) * (nx + 1) + 1) * sizeof(double); }
+}  // namespace
+
+// Plan of the double sweep: Q points per thread, TY lines per tile, CZ planes per chunk.  Cost model (checked against
+// tools/micro/box2_proto on MI355X: 216^3 Q4/TY14/CZ14 57 us, Q3/TY10/CZ14 94 us, 108x216x216 Q4/TY33/CZ6 34 us, Q2/TY14/CZ14 38 us):
+// a workgroup's time ~ (CZ + 2) steps x Q points, the launch takes ceil(workgroups / 256 CUs) rounds of it.
+bool box2_plan(DevCsr &A)
+{
+    A.box_q = A.box_ty = A.box_cz = 0;
+    const int nx = A.box_nx, ny = A.box_ny, nz = A.box_nz;
+    if (nx < 2 || ny < 1 || nz < 1) return false;
+    long best = -1;
+    for (int Q = 2; Q <= 4; ++Q) {
+        int TY = std::min(ny, Q * kBoxBlock / nx - 4);
+        while (TY >= 1 && box2_lds_bytes(nx, TY) > 65536) --TY;
+        if (TY < 1) continue;
+        const int ytiles = (ny + TY - 1) / TY;
+        for (int zch = 1; zch <= nz; ++zch) {
+            const int CZ = (nz + zch - 1) / zch;
+            const int chunks = (nz + CZ - 1) / CZ;
+            const long wgs = (long)ytiles * chunks, rounds = (wgs + 255) / 256;
+            const long cost = rounds * (CZ + 2) * Q;
+            if (best < 0 || cost < best) {
+                best = cost;
+                A.box_q = Q;
+                A.box_ty = TY;
+                A.box_cz = CZ;
+            }
+        }
+    }
+    return A.box_q > 0;
+}
+
+bool box2_applies(const DevCsr &A, const KernelConfig &c)
+{
+    return c.box2 != 0 && A.box_on && A.box_q > 0 && csr_family(A, c) == FAM_SDIA_TAB;
+}
+
+void launch_box2(const DevCsr &A, const double *x, const double *b, double *y, double omega, bool finest, hipStream_t st)
+{
+    BoxArgs g;
+    g.nx = A.box_nx;
+    g.ny = A.box_ny;
+    g.nz = A.box_nz;
+    g.TY = A.box_ty;
+    g.CZ = A.box_cz;
+    g.ytiles = (g.ny + g.TY - 1) / g.TY;
+    for (int u = 0; u < 7; ++u) g.c[u] = A.sd_tab.cval[u];
+    g.omega = omega;
+    const int chunks = (g.nz + g.CZ - 1) / g.CZ;
+    const dim3 grid(g.ytiles * chunks), block(kBoxBlock);
+    const size_t lds = box2_lds_bytes(g.nx, g.TY);
+#define SPARSH_LAUNCH_BOX(Q_)                                                                        \
+    do {                                                                                             \
+        if (finest) hipLaunchKernelGGL((sdia_box2_kernel<Q_, 1>), grid, block, lds, st, g, x, b, y); \
+        else hipLaunchKernelGGL((sdia_box2_kernel<Q_, 0>), grid, block, lds, st, g, x, b, y);        \
+    } while (0)
+    if (A.box_q == 4) SPARSH_LAUNCH_BOX(4);
+    else if (A.box_q == 3) SPARSH_LAUNCH_BOX(3);
+    else SPARSH_LAUNCH_BOX(2);
+#undef SPARSH_LAUNCH_BOX
+}
 
 bool resid_pair_applies(const DevCsr &A, const KernelConfig &c)
 {

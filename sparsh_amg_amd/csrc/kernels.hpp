@@ -73,6 +73,13 @@ struct DevCsr {
     unsigned long long *sd_tmask = nullptr;
     int *sd_tconf = nullptr;
     bool has_sdia() const { return sd_ptr != nullptr; }
+    // box grid: the table is the 7-point stencil (-plane, -line, -1, 0, +1, +line, +plane) of an nx x ny x nz grid in lexicographic
+    // order, every slice conforms and a row lacks exactly the neighbours that would lie outside the box.  Such a level can run
+    // two Jacobi sweeps in one pass over its vectors (sdia_box2_kernel); box_q/ty/cz = the launch plan (box2_plan), box_on =
+    // the setup's verdict that the double sweep beats two single ones on this level (timed there, or forced)
+    int box_nx = 0, box_ny = 0, box_nz = 0;
+    int box_q = 0, box_ty = 0, box_cz = 0;
+    bool box_on = false;
     // rank-local blocks: slices whose rows touch no halo column (interior) / some (boundary)
     int *int_list = nullptr, *bnd_list = nullptr;
     int nint = 0, nbnd = 0;
@@ -100,6 +107,8 @@ struct KernelConfig {
     bool fuse_cg_zero = true; // PCG: the cg_update kernel also writes the V-cycle's zero-guess sweep of level 0
     int alt_dir = 1;          // consecutive sweeps of a smoothing leg walk the level in alternating directions (CsrArgs::reverse):
                               // 0 never, 1 where a sweep streams more than 640 MB (2.5x the Infinity Cache), 2 always
+    int box2 = 1;              // box-grid levels (DevCsr::box_nx): two Jacobi sweeps per launch (sdia_box2_kernel): 0 never, 1 where the
+                               // setup measured it faster than two single sweeps (levels of >= 400 000 rows), 2 wherever a plan exists
     bool const_diag = true;    // levels whose diagonal is one constant: the vector kernels that divide by it (zero-guess sweeps fused
                                // into cg_update / the restriction) take it as an argument instead of streaming diag[]
     bool fuse_prolong = true;  // V-cycle: the last post-sweep of a level adds its result to the finer level's iterate itself
@@ -175,6 +184,11 @@ int build_col16(const int *rowptr, const int *col, const int *rec, int nblk, uns
 // `finest`: launch on the finest level (selects a separately named kernel instance for profilers)
 int launch_csr(const DevCsr &A, CsrOp op, const CsrArgs &a, bool finest, hipStream_t st, const KernelConfig &cfg);
 CsrFamily csr_family(const DevCsr &A, const KernelConfig &cfg);
+// Double Jacobi sweep y = J(J(x)) on a box-grid level (DevCsr::box_nx > 0), bitwise what two OP_JACOBI launches give.
+// box2_plan fills box_q/ty/cz (false: no plan -- lines too long for the LDS region); box2_applies = the level runs it under cfg
+bool box2_plan(DevCsr &A);
+bool box2_applies(const DevCsr &A, const KernelConfig &cfg);
+void launch_box2(const DevCsr &A, const double *x, const double *b, double *y, double omega, bool finest, hipStream_t st);
 // OP_RESID_PAIR over the whole of A (a.y = coarse rhs, a.y2 = coarse iterate, a.d = coarse diagonal); applies to operators
 // that run the table kernel under cfg -- resid_pair_applies says whether launch_resid_pair may be called
 bool resid_pair_applies(const DevCsr &A, const KernelConfig &cfg);

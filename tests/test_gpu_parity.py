@@ -770,3 +770,71 @@ def test_constant_diagonal_levels_bitwise():
     B = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET))
     assert not B.level_constant_diagonal(0)[0]
     B.close()
+
+
+@pytest.mark.parametrize("dims", [(30, 30, 30), (19, 11, 23), (64, 9, 11), (5, 40, 31), (100, 60, 40), (300, 20, 12), (700, 6, 5)])
+def test_double_sweep_box_grid_bitwise(dims):
+    """sdia_box2_kernel: two Jacobi sweeps per launch on box-grid levels (temporal blocking through LDS).  Forced on
+    (set_double_sweep(2)) for grids whose tiles are clipped in every direction; against the oracle's sweeps, bit for bit, for
+    even and odd sweep counts, from a zero guess, on every level that qualifies; whole solves against the same handle with
+    single sweeps: same histories and solutions, bit for bit."""
+    nx, ny, nz = dims
+    rp, ci, v = problems.poisson3d(nx, ny, nz)
+    n = len(rp) - 1
+    A = sa.sp_matrix_mg(rp, ci, v).set_double_sweep(2).setup(sa.default_params(**QUIET, max_iter=60))
+    O = oracle.Csr(rp, ci, v)
+    H = oracle.Hierarchy(O)
+    info = [A.level_double_sweep(l) for l in range(A.nlevels)]
+    assert info[0]["on"] and info[0]["grid"] == [nx, ny, nz], info[0]
+    rng = np.random.default_rng(81)
+    boxes = [l for l in range(A.nlevels - 1) if info[l]["on"]]
+    for l in boxes:
+        nl = A.level_info(l)["nrow"]
+        g = info[l]["grid"]
+        assert g[0] * g[1] * g[2] == nl and A.level_kernel(l) == "sdia_tab_kernel"
+        x, b = rng.standard_normal(nl), rng.standard_normal(nl)
+        Ol = H.A(l)
+        for sweeps in (2, 3, 4, 7):
+            assert np.array_equal(A.op_jacobi(l, b, x, sweeps), oracle.jacobi(Ol, b, x, sweeps - 1)), (dims, l, sweeps)
+        assert np.array_equal(A.op_jacobi(l, b, np.zeros(nl), 7, x_is_zero=True), oracle.jacobi(Ol, b, np.zeros(nl), 6)), (dims, l)
+    b = rng.standard_normal(n)
+    out = {}
+    for mode in (2, 0):
+        A.set_double_sweep(mode)
+        assert A.level_double_sweep(0)["on"] == (mode == 2)
+        for method in ("amg", "pcg"):
+            x = np.zeros(n)
+            h, rc = A.solve(method, b, x)
+            assert rc in (0, sa.SPARSH_ENOCONV) and len(h) > 0
+            out[(mode, method)] = (np.array(h), x)
+    for method in ("amg", "pcg"):
+        assert np.array_equal(out[(2, method)][0], out[(0, method)][0]), (dims, method)
+        assert np.array_equal(out[(2, method)][1], out[(0, method)][1]), (dims, method)
+    A.close()
+
+
+def test_double_sweep_needs_a_box_grid():
+    """A 7-point operator that is not the stencil of a full box (one interior coupling removed) keeps the single sweeps;
+    so does a 2D grid; the default mode leaves small levels alone."""
+    rp, ci, v = problems.poisson3d(20)
+    import scipy.sparse as sp
+
+    M = sp.csr_matrix((v, ci, rp)).tolil()
+    r = 20 * 20 * 10 + 20 * 10 + 10
+    M[r, r + 1] = 0.0
+    M[r + 1, r] = 0.0
+    M = M.tocsr()
+    M.eliminate_zeros()
+    M.sort_indices()
+    A = sa.sp_matrix_mg(M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data).set_double_sweep(2).setup(sa.default_params(**QUIET))
+    assert not A.level_double_sweep(0)["on"] and A.level_double_sweep(0)["grid"] == [0, 0, 0]
+    A.close()
+    rp, ci, v = problems.poisson2d(150)
+    B = sa.sp_matrix_mg(rp, ci, v).set_double_sweep(2).setup(sa.default_params(**QUIET))
+    assert not B.level_double_sweep(0)["on"]
+    B.close()
+    rp, ci, v = problems.poisson3d(30)
+    D = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET))  # default: timed, levels of >= 400 000 rows only
+    d = D.level_double_sweep(0)
+    assert d["grid"] == [30, 30, 30] and not d["on"] and d["double_sweep_us"] == 0.0
+    D.close()

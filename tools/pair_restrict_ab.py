@@ -1,7 +1,7 @@
 """Same-process A/B of the fused residual + restriction launch (sparsh_set_paired_restriction) or of the fused last post-sweep
 + prolongation (sparsh_set_fused_prolongation) inside the PCG iteration.
 
-    python tools/pair_restrict_ab.py [--what pair|prolong|diag] [--n 216] [--dim 3] [--iters 96] [--reps 3] [--out FILE]
+    python tools/pair_restrict_ab.py [--what pair|prolong|diag|box2] [--n 216] [--dim 3] [--iters 96] [--reps 3] [--out FILE]
 
 One handle, one hierarchy; the setting is toggled between timed runs of `iters` PCG iterations (restart every 48, as bench.py
 does), alternating on / off so that drift of the box hits both sides alike.  Prints it/s per run and the median of each side.
@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--iters", type=int, default=96)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--out", default=None)
-    ap.add_argument("--what", default="pair", choices=["pair", "prolong", "diag"])
+    ap.add_argument("--what", default="pair", choices=["pair", "prolong", "diag", "box2"])
     args = ap.parse_args()
     rp, ci, v = problems.poisson3d(args.n) if args.dim == 3 else problems.poisson2d(args.n)
     n = len(rp) - 1
@@ -35,6 +35,9 @@ def main():
     if args.what == "pair":
         paired = [l for l in range(A.nlevels - 1) if A.level_paired(l)]
         toggle = A.set_paired_restriction
+    elif args.what == "box2":
+        paired = [(l, A.level_double_sweep(l)) for l in range(A.nlevels) if A.level_double_sweep(l)["grid"][0] > 0]
+        toggle = lambda on: A.set_double_sweep(1 if on else 0)  # noqa: E731
     elif args.what == "diag":
         paired = [l for l in range(A.nlevels) if A.level_constant_diagonal(l)[0]]
         toggle = A.set_constant_diagonal
