@@ -299,7 +299,14 @@ def main():
         dvec = [0 if H.level_constant_diagonal(l)[0] else 8 for l in range(len(levels))]  # bytes per row of a level's diag[] stream where it is read
         for l, (nl, nnzl, pn, pnnz) in enumerate(levels[:-1]):
             ncl = levels[l + 1][0]
-            total += (2 * sweeps - 1) * layout_bytes(H, nl, nnzl, l, 3)
+            if world == 1 and H.level_double_sweep(l)["on"]:
+                # both legs: (sweeps - 1) plain sweeps run as pairs (one pass over x, b, y: 24 B per row), the rest -- and the last
+                # post-sweep, which carries the dot / the prolongation -- as single sweeps
+                pairs = 2 * ((sweeps - 1) // 2)
+                singles = 2 * ((sweeps - 1) % 2) + 1
+                total += pairs * 24 * nl + singles * layout_bytes(H, nl, nnzl, l, 3)
+            else:
+                total += (2 * sweeps - 1) * layout_bytes(H, nl, nnzl, l, 3)
             if l > 0 and not prev_paired:
                 total += (16 + dvec[l]) * nl
             prev_paired = H.level_paired(l)
@@ -318,8 +325,15 @@ def main():
         total += layout_bytes(H, n0, nnz0, 0, 2) + (56 + dvec[0]) * n0 + 24 * n0
         return total
 
+    def double_sweep(H):
+        return world == 1 and mode == "single" and H.level_double_sweep(0)["on"]
+
     def kernel_label(H):
         nt, remap = H.level_placement(0)
+        if double_sweep(H):
+            d = H.level_double_sweep(0)
+            return (f"sdia_box2_kernel<Q={d['points_per_thread']}, TAG=1> (TWO fused Jacobi sweeps per launch on the finest level: {d['lines_per_tile']} grid lines x "
+                    f"{d['planes_per_chunk']} planes per workgroup, first sweep's plane in LDS)")
         return f"{H.level_kernel(0)}<OP_JACOBI=2, NT={'true' if nt else 'false'}, TAG=1> (fused Jacobi sweep, finest level; XCD remap mode {remap})"
 
     pr = A.profile_read()
@@ -327,6 +341,29 @@ def main():
     fmt, stored = A.level_format(0)
     slots, vblocks, meta_bytes = A.level_layout(0)
     fmt_bytes = layout_bytes(A, pr["nrow"], pr["nnz"])
+    dbl = double_sweep(A)
+    if dbl:
+        # one launch = two sweeps in one pass: x and b read, the second sweep's result written -- no matrix stream, no masks
+        fmt_bytes = 24 * pr["nrow"]
+        jac_bytes *= 2
+    single_sweeps = None
+    if dbl:
+        # the same handle, same hierarchy, with the double sweep switched off (outside the timed region): what the launch-per-sweep
+        # path gives on this box in this process; histories are bitwise the same (tests/test_gpu_parity.py)
+        try:
+            A.set_double_sweep(0)
+            run_steps(min(args.steps, 24))
+            barrier()
+            ts0 = time.perf_counter()
+            run_steps(args.steps)
+            barrier()
+            ts1 = time.perf_counter()
+            single_sweeps = {"iterations_per_s": round(args.steps / (ts1 - ts0), 2), "steps": args.steps,
+                             "note": "sparsh_set_double_sweep(0): every Jacobi sweep a launch of its own (the round-2 path)"}
+        except Exception as e:  # noqa: BLE001
+            single_sweeps = {"error": repr(e)}
+        finally:
+            A.set_double_sweep(1)
     roof = None
     if pr["launches"] > 0:
         avg = pr["seconds"] / pr["launches"]
@@ -346,13 +383,29 @@ def main():
             "csr_model_frac": round(jac_bytes / avg / 1e9 / HBM_PEAK_GBS, 4),
             "layout": {"slots": slots, "value_blocks": vblocks, "constant_slots": slots - vblocks, "descriptor_bytes": meta_bytes} if fmt == 3 else None,
         }
+        if dbl:
+            single = layout_bytes(A, pr["nrow"], pr["nnz"])
+            roof["sweeps_per_launch"] = 2
+            roof["us_per_sweep"] = round(avg * 1e6 / 2, 2)
+            roof["double_sweep"] = A.level_double_sweep(0)
+            roof["note"] = ("the dominant kernel is the double sweep (sparsh_set_double_sweep; DESIGN.md section 4): ONE launch performs TWO Jacobi sweeps of the finest level in one "
+                            "pass over x, b and the result (temporal blocking: the first sweep's plane stays in LDS, its halo is recomputed). achieved/frac price a LAUNCH with the "
+                            "bytes it has to move -- bytes_per_launch = 24 B per row: x and b read, the second sweep's result written; the operator itself is seven kernel arguments. "
+                            f"Two launches of the single-sweep kernel this replaces move 2 x {single} B. traffic = PMC bytes per launch of this kernel (halo lines and planes "
+                            "are read by two workgroups; what the L2s and the Infinity Cache do not absorb shows there). csr_model_* price the launch with SURVEY section 8d's CSR "
+                            "model for TWO sweeps (2 x (12*nnz + 36*n)): an effective rate, not a bandwidth. With 16 waves per CU and two workgroup barriers per plane the kernel "
+                            "is bound by fp64 VALU issue (7 mul + 7 add + an IEEE division per row and sweep, 2.3 sweep-equivalents per launch with the recomputed halo) about "
+                            "as much as by HBM; avg_us is measured inside the solve over runs of consecutive double-sweep launches")
         if world == 1 and mode == "single":
             # the same kernel launched back to back in this process (outside the timed region): the in-solve figure above varies
             # from process to process with the physical placement of a working set the size of the Infinity Cache
             try:
                 pinfo = A.placement_info()
                 # on the buffers the solve uses (the setup's placement search timed exactly this), else on fresh ones
-                b2b = pinfo["chosen_us"] * 1e-6 if pinfo["triples"] > 0 else A.bench_op("jacobi_pingpong", 0, 20)
+                if dbl:  # (the placement search times the kernel the legs run and reports us per SWEEP)
+                    b2b = 2 * pinfo["chosen_us"] * 1e-6 if pinfo["triples"] > 0 else A.bench_op("jacobi_double", 0, 20)
+                else:
+                    b2b = pinfo["chosen_us"] * 1e-6 if pinfo["triples"] > 0 else A.bench_op("jacobi_pingpong", 0, 20)
                 roof["back_to_back_us"] = round(b2b * 1e6, 2)
                 roof["back_to_back_frac"] = round(fmt_bytes / b2b / 1e9 / HBM_PEAK_GBS, 4)
                 roof["note"] += (". avg_us is measured inside the solve; back_to_back_us is the same kernel ping-ponging between two vectors alone. "
@@ -506,8 +559,9 @@ def main():
 
             res = pmc_traffic.summarize(os.path.join(tmpd, "fetch"), os.path.join(tmpd, "write"), None, args.grid, lay, quiet=True)
             measured_kernel = json.load(open(lay)).get("kernel")
-            if measured_kernel != A.level_kernel(0):
-                raise RuntimeError(f"PMC child ran {measured_kernel}, the timed run {A.level_kernel(0)}")
+            want_kernel = "sdia_box2_kernel" if dbl else A.level_kernel(0)
+            if measured_kernel != want_kernel:
+                raise RuntimeError(f"PMC child ran {measured_kernel}, the timed run {want_kernel}")
             traffic = float(res["jacobi_fine_bytes_per_launch"])
             avg = roof["avg_us"] * 1e-6
             roof["traffic"] = round(traffic)
@@ -687,6 +741,9 @@ def main():
                 "paired_restriction_levels": [l for l in range(len(levels) - 1) if A.level_paired(l)],
                 # levels whose last post-sweep prolongates into the level above itself (no prolongation launch)
                 "fused_prolongation_levels": [l for l in range(len(levels)) if A.level_prolong_fused(l)],
+                # box-grid levels whose smoothing legs run two sweeps per launch, with the setup's timings (us per pair of sweeps)
+                "double_sweep_levels": ({l: A.level_double_sweep(l) for l in range(len(levels)) if A.level_double_sweep(l)["on"]} if world == 1 else None),
+                "single_sweeps_same_process": single_sweeps,
                 "parallelism": "1 GPU" if world == 1 else (mode_note or (
                     f"{world} GPUs, one process each: contiguous row blocks on the {partitioned_levels} finest levels; deep-halo smoothing "
                     f"(sweeps+1 ghost layers per block, ONE ghost-layer exchange per smoothing leg, grouped ncclSend/ncclRecv of packed "

@@ -360,7 +360,8 @@ int sparsh_op_axpby(sparsh_handle h, int n, double a, const double *x, double bc
  * on the engine's stream; returns average seconds per launch.  op: 0 spmv, 1 fused jacobi
  * sweep, 2 residual, 3 restrict, 4 prolong, 5 coarse GEMV, 6 dot, 7 axpby, 8 int32 copy (4-byte
  * stream, calibrates the profiler's byte counters), 9 fused Jacobi sweeps ping-ponging between two vectors (the
- * access pattern of a smoothing leg), 10 the same on the level's own resident x / x2 / r buffers. */
+ * access pattern of a smoothing leg), 10 the same on the level's own resident x / x2 / r buffers, 11 double sweeps
+ * (sparsh_set_double_sweep) ping-ponging on those buffers: seconds per launch = per PAIR of sweeps. */
 int sparsh_bench_op(sparsh_handle h, int op, int level, int reps, double *avg_seconds);
 
 /* device memory helpers so a host language needs no HIP binding of its own */

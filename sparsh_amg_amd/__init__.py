@@ -725,7 +725,7 @@ class sp_matrix_mg:
 
     def bench_op(self, op, level=0, reps=20):
         ops = {"spmv": 0, "jacobi": 1, "residual": 2, "restrict": 3, "prolong": 4, "coarse": 5, "dot": 6, "axpby": 7, "copy_int": 8,
-               "jacobi_pingpong": 9, "jacobi_pingpong_resident": 10}
+               "jacobi_pingpong": 9, "jacobi_pingpong_resident": 10, "jacobi_double": 11}
         sec = C.c_double()
         _check(lib.sparsh_bench_op(self._h, ops[op] if isinstance(op, str) else op, level, reps, C.byref(sec)))
         return sec.value

@@ -1194,10 +1194,17 @@ int sparsh_bench_op(sparsh_handle h, int op, int level, int reps, double *avg_se
             ++flip;
             launch_csr(L.A, OP_JACOBI, a, L.fine, st, E.kernel_cfg());
         } break;
+        case 11: {  // double sweeps (sdia_box2_kernel) ping-ponging on the level's resident buffers, as a smoothing leg issues them
+            static thread_local int flip2 = 0;
+            double *xa = (flip2 & 1) ? L.x2 : L.x, *xb = (flip2 & 1) ? L.x : L.x2;
+            ++flip2;
+            launch_box2(L.A, xa, L.r, xb, E.params().omega, L.fine, st);
+        } break;
         default: break;
         }
     };
-    if (op < 0 || op > 10) return fail(SPARSH_EINVAL, "unknown op");
+    if (op < 0 || op > 11) return fail(SPARSH_EINVAL, "unknown op");
+    if (op == 11 && (E.distributed() || !box2_applies(L.A, E.kernel_cfg()))) return fail(SPARSH_ESTATE, "the level does not run double sweeps (sparsh_level_double_sweep)");
     for (int i = 0; i < 3; ++i) run();
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);

@@ -738,7 +738,9 @@ void Engine::tune_placement()
     const double t_begin = omp_get_wtime();
     // stop at the first triple within 4 % of what the sweep's own 24 bytes per row take at 5.8 TB/s (a cache-resident run);
     // otherwise the best of at most 260 triples, the owned buffers first
-    const double good_us = (double)L.n * 24.0 / 5.8e12 * 1e6 * 1.04;
+    // (double sweeps: the probe reports us per sweep = half a launch; 0.6 of the single sweep's figure is a cache-friendly run,
+    // tools/micro/box2_proto 57 us per launch at 216^3)
+    const double good_us = (double)L.n * 24.0 / 5.8e12 * 1e6 * 1.04 * (box2_applies(L.A, cfg_) ? 0.6 : 1.0);
     double best = 1e30, worst = 0.0;
     int bi = 0, bj = 1, bk = 2;
     const int nb = (int)buf.size();

@@ -45,7 +45,8 @@ def run(grid=N_GRID, cfg=None, no_fold=False, layout_out=None, fem=0, idx16=None
     cfg = cfg or os.environ.get("SPARSH_PMC_CFG")  # "kind,vec,nt,remap": override the per-operator policy (diagnostics)
     if cfg:
         A.set_kernel_config(*[int(t) for t in cfg.split(",")])
-    for op in ("axpby", "dot", "copy_int", "jacobi"):
+    double = A.level_double_sweep(0)["on"]  # the finest level's smoothing legs run double sweeps: that kernel is the one measured
+    for op in ("axpby", "dot", "copy_int", "jacobi_double" if double else "jacobi"):
         A.bench_op(op, 0, 4)
     if iters > 0:
         # whole AMG-PCG iterations between marker launches (SURVEY 8d metric (ii): HBM bytes of the whole V-cycle + Krylov
@@ -72,7 +73,7 @@ def run(grid=N_GRID, cfg=None, no_fold=False, layout_out=None, fem=0, idx16=None
         layout_out = os.path.join(root, "gpurun_out", "pmc_layout.json")
     with open(layout_out, "w") as f:
         b16, nblk = A.level_index16(0)
-        json.dump({"slots": slots, "value_blocks": vblocks, "descriptor_bytes": meta, "kernel": A.level_kernel(0), "grid": grid,
+        json.dump({"slots": slots, "value_blocks": vblocks, "descriptor_bytes": meta, "kernel": "sdia_box2_kernel" if double else A.level_kernel(0), "grid": grid,
                    "nrow": len(rp) - 1, "nnz": int(rp[-1]), "stored_entries": A.level_format(0)[1], "iters": iters,
                    "index16_blocks": b16, "row_blocks": nblk}, f)
 
@@ -91,6 +92,9 @@ def collect(d, jacobi_kernel=None):
             key = "dot"
         elif "copy_int_kernel" in name:
             key = "copy_int"
+        elif jacobi_kernel == "sdia_box2_kernel" and "sdia_box2_kernel<" in name and ", 1>" in name:
+            key = "jacobi"
+            out["_kind"] = [4.0]
         elif ("sdia_kernel<2" in name or "sdia_tab_kernel<2" in name or "sdia_ord_kernel<2" in name or "sell_kernel<2" in name
               or "csr_block_kernel<2" in name or "csr_rowlane_kernel<2" in name or "csr_rowlane16_kernel<2" in name) and ", 1>" in name \
                 and (jacobi_kernel is None or (jacobi_kernel + "<") in name):
@@ -171,6 +175,10 @@ def summarize(fetch_dir, write_dir, out_path, grid=N_GRID, layout_path=None, qui
         val_bytes = 512 * layout["value_blocks"]
         meta_bytes = layout.get("descriptor_bytes", 24 * layout["slots"])
     alg = 12 * nnz + 36 * n
+    if kind == 4:  # double sweep on a box grid: no matrix stream at all; what one launch (= two sweeps) has to move: x and b in, y out
+        val_bytes = 0
+        meta_bytes = 0
+        alg = 24 * n
     res = {
         "_how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); counter KiB -> bytes; per-width correction from "
                 "calibration kernels of known size run in the same process (tools/pmc_traffic.py)",
@@ -183,7 +191,8 @@ def summarize(fetch_dir, write_dir, out_path, grid=N_GRID, layout_path=None, qui
         "jacobi_fine_algorithmic_bytes": alg,
         "ratio_traffic_over_algorithmic": (read_total + write["jacobi"] * wf8) / alg,
         "kernel_family": {3: "sdia_kernel (sliced diagonals)", 2: "sell_kernel (sliced ELL)", 0: "CSR-stream (csr_block_kernel / csr_rowlane_kernel)",
-                          1: "CSR-stream, 16-bit delta column indices (csr_rowlane16_kernel)"}.get(kind),
+                          1: "CSR-stream, 16-bit delta column indices (csr_rowlane16_kernel)",
+                          4: "sdia_box2_kernel (two Jacobi sweeps per launch on a box grid; algorithmic bytes = 24 n per LAUNCH)"}.get(kind),
         "layout": layout,
         "x_vector_fetches_per_entry": (bytes8 - val_bytes - meta_bytes - 8 * n) / (8 * n),
     }
