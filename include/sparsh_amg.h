@@ -167,7 +167,11 @@ int sparsh_set_alternate_sweeps(sparsh_handle h, int mode);
  * level's residual vector is neither written nor read back and one launch replaces two (parallel::store_residual +
  * parallel::transfer_residual, src/AMG_cycle_utilities.cpp:115-123 and :97-104).  Same expressions in the same order --
  * results are bitwise unchanged.  enable: 1 (default) / 0 (A/B).
- * sparsh_level_paired: whether a level of the built hierarchy takes this path under the current configuration. */
+ * Box-grid levels (sparsh_level_double_sweep) whose aggregates pair a grid point with its neighbour one line or one plane up get the
+ * same fusion from a kernel of their own: one thread per aggregate computes both residuals from the seven-point stencil; neither r nor
+ * R is touched.
+ * sparsh_level_paired: whether a level of the built hierarchy takes this path under the current configuration: 0 no, 1 row pairs
+ * (2J, 2J+1), 2 / 3 box-grid level paired along y / z. */
 int sparsh_set_paired_restriction(sparsh_handle h, int enable);
 /* Up-leg: with an aggregation prolongator every fine row has exactly one coarse owner, so the last post-smoothing sweep of
  * level l can add its result to the rows of level l - 1 it owns (x_f = 1.0 * x_c + x_f, parallel::transfer_solution,

@@ -388,10 +388,10 @@ class sp_matrix_mg:
         return self
 
     def level_paired(self, level):
-        """Whether `level` of the built hierarchy takes the fused residual + restriction launch."""
+        """Whether `level` takes the fused residual + restriction launch: 0 no, 1 row pairs (2J, 2J+1), 2 / 3 box grid paired along y / z."""
         v = C.c_int(0)
         _check(lib.sparsh_level_paired(self._h, int(level), C.byref(v)))
-        return bool(v.value)
+        return v.value
 
     def set_index_compression(self, mode=1):
         """16-bit delta-coded column indices for the CSR-stream family (call before setup); see sparsh_set_index_compression."""

@@ -488,7 +488,7 @@ int sparsh_level_paired(sparsh_handle h, int level, int *paired)
     REQUIRE_READY(h);
     REQUIRE_LEVEL(h, level);
     if (!paired) return fail(SPARSH_EINVAL, "null output");
-    *paired = h->eng->level_paired(level) ? 1 : 0;
+    *paired = h->eng->level_paired(level);
     return SPARSH_OK;
 }
 

@@ -654,7 +654,8 @@ void Engine::tune_box2()
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) continue;
         CsrArgs a;
-        a.b = L.r;  // (scratch: any vector of the level's length)
+        a.b = L.r;  // (scratch: any vector of the level's length; ones, so that the sweeps work on ordinary numbers)
+        launch_fill(L.n, 1.0, L.r, st_);
         a.d = L.diag;
         a.omega = prm_.omega;
         auto timed = [&](bool fused) -> double {
@@ -680,6 +681,9 @@ void Engine::tune_box2()
         L.box_single_us = timed(false);
         L.box_double_us = timed(true);
         L.A.box_on = L.box_double_us < 0.97 * L.box_single_us;
+        (void)hipMemsetAsync(L.x, 0, (size_t)L.n * 8, st_);
+        (void)hipMemsetAsync(L.x2, 0, (size_t)L.n * 8, st_);
+        (void)hipMemsetAsync(L.r, 0, (size_t)L.n * 8, st_);
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
     }
@@ -736,6 +740,9 @@ void Engine::tune_placement()
         return (double)ms * 1e3 / 8.0;
     };
     const double t_begin = omp_get_wtime();
+    // the probes sweep ordinary numbers (ones), not the zeros a fresh setup leaves: a zero residual takes the plain-division branch of
+    // the double sweep (div_const), which the solve never sees
+    for (double *q : buf) launch_fill(L.n, 1.0, q, st_);
     // stop at the first triple within 4 % of what the sweep's own 24 bytes per row take at 5.8 TB/s (a cache-resident run);
     // otherwise the best of at most 260 triples, the owned buffers first
     // (double sweeps: the probe reports us per sweep = half a launch; 0.6 of the single sweep's figure is a cache-friendly run,
@@ -1189,6 +1196,25 @@ int Engine::setup(const sparsh_params &p)
                     for (int J = 0; pairs && J < nc; ++J) pairs = h.R.rowptr[J] == 2 * J;
                     for (int j = 0; pairs && j < n; ++j) pairs = h.R.col[j] == j && h.P.col[j] == j / 2;
                     d.pair_aggregates = pairs;
+                    if (!pairs && d.A.box_nx > 0 && n == 2 * nc && h.R.rowptr[nc] == n) {
+                        // box-grid level: aggregate J, lexicographic in the coarse box, = point (i, 2j', k) + (i, 2j'+1, k) (axis 1) or
+                        // (i, j, 2k') + (i, j, 2k'+1) (axis 2)?
+                        const int bx = d.A.box_nx, by = d.A.box_ny, bz = d.A.box_nz;
+                        for (int axis = 1; axis <= 2 && d.pair_axis == 0; ++axis) {
+                            if ((axis == 1 ? by : bz) % 2 != 0) continue;
+                            const int cny = axis == 1 ? by / 2 : by, stride = axis == 1 ? bx : bx * by;
+                            for (int rev = 0; rev <= 1 && d.pair_axis == 0; ++rev) {  // (numbered from the near or from the far end of the box)
+                                bool ok = true;
+                                for (int J = 0; ok && J < nc; ++J) {
+                                    const int i = J % bx, t = J / bx, cj = t % cny, ck = t / cny;
+                                    const int f1 = i + bx * ((axis == 1 ? 2 * cj : cj) + by * (axis == 2 ? 2 * ck : ck));
+                                    const int j0 = h.R.rowptr[rev ? nc - 1 - J : J];
+                                    ok = h.R.rowptr[(rev ? nc - 1 - J : J) + 1] - j0 == 2 && h.R.col[j0] == f1 && h.R.col[j0 + 1] == f1 + stride;
+                                }
+                                if (ok) d.pair_axis = rev ? -axis : axis;
+                            }
+                        }
+                    }
                     if (!pairs && nc > 0) {  // aggregates of one or two rows (pairwise matching): their rows, for the fused prolongation
                         std::vector<int> mem((size_t)2 * nc, -1);
                         bool two = h.R.rowptr[nc] == n && h.P.rowptr[n] == n;
@@ -1589,6 +1615,10 @@ void Engine::op_residual(int l, const double *b, const double *x, double *r)
 
 void Engine::op_residual_restrict(int l, const double *b, const double *x, double *bc, double *xc)
 {
+    if (!lev_[l].pair_aggregates && lev_[l].pair_axis != 0) {
+        launch_box_resid_pair(lev_[l].A, lev_[l].pair_axis, x, b, diag_stream(lev_[l + 1]), lev_[l + 1].diag_const, prm_.omega, bc, xc, st_);
+        return;
+    }
     CsrArgs a;
     a.x = x;
     a.b = b;

@@ -36,6 +36,8 @@ struct DevLevel {
     bool P_is_aggregation = false;
     int *members = nullptr;        // aggregates of at most two rows that are not such pairs: (first, second or -1) per coarse row, for the
                                    // coarser level's last post-sweep to prolongate into this level itself (OP_JACOBI_PROLONG)
+    int pair_axis = 0;             // box-grid level whose aggregate J (lexicographic in the coarse box; < 0: from its far end) = grid point + its neighbour one line (1) /
+                                   // one plane (2) up: residual + restriction without r and R (box_resid_pair_kernel)
     bool pair_aggregates = false;  // aggregate J = fine rows (2J, 2J+1) in R's stored order: residual + restriction fuse (OP_RESID_PAIR)
     double *diag = nullptr;
     double box_single_us = 0.0, box_double_us = 0.0;  // setup timing of two single sweeps / one double sweep (tune_box2), 0 = not timed
@@ -117,9 +119,13 @@ public:
         return F.P_is_aggregation && !F.deep && (F.pair_aggregates || F.members) && F.R.nrow == lev_[l].n;
     }
     // whether level l's residual, restriction and the next level's zero-guess sweep run as one launch (OP_RESID_PAIR)
-    bool level_paired(int l) const
+    // 0 no; 1 aggregates = row pairs (2J, 2J+1): OP_RESID_PAIR of the table kernel; 2 / 3 box-grid level paired along y / z
+    int level_paired(int l) const
     {
-        return l + 2 < (int)lev_.size() && lev_[l].pair_aggregates && prm_.sweeps > 0 && !dist_ && resid_pair_applies(lev_[l].A, cfg_);
+        if (!(l + 2 < (int)lev_.size() && prm_.sweeps > 0 && !dist_ && cfg_.pair_restrict)) return 0;
+        if (lev_[l].pair_aggregates && resid_pair_applies(lev_[l].A, cfg_)) return 1;
+        if (lev_[l].pair_axis != 0 && lev_[l].A.box_nx > 0 && csr_family(lev_[l].A, cfg_) == FAM_SDIA_TAB) return 1 + std::abs(lev_[l].pair_axis);
+        return 0;
     }
     // average seconds of one communication step alone (collective: every rank calls it): what = 0 halo
     // exchange of level `level`'s operator, 1 the 16-byte all-reduce of the fused scalars, 2 the

@@ -1235,6 +1235,42 @@ __global__ __launch_bounds__(kTileBlock) void sdia_tile_kernel(int nrow, int xle
 // Reads per row and double sweep: x (TY+4)/TY * (CZ+3)/CZ, b (TY+2)/TY * (CZ+2)/CZ, one store: ~30 B instead of 48.
 constexpr int kBoxBlock = 1024;
 
+// a / b for a divisor known before the loop: the compiler's own fp64 division sequence -- v_div_scale of both operands, v_rcp_f64 and two
+// Newton steps on the scaled divisor, q0 = a_s r, rem = fma(-b_s, q0, a_s), v_div_fmas, v_div_fixup -- with the part that depends on b
+// alone, the refined reciprocal of the scaled divisor, computed once per thread instead of once per row and sweep (5 of the 12
+// instructions, among them the quarter-rate v_rcp_f64).  Where v_div_scale would scale b differently for this a (denormal or zero
+// operands, exponents ~2^1000 apart: not residual-sized numbers) the whole wave takes the plain division.  Same instructions on the
+// same operands, hence bitwise the plain division's result (tools/micro/divtest: 1.7e8 random quotients incl. denormals, infinities
+// and NaNs against the compiler's division and against the host's, no difference).
+struct DivConst {
+    double b, bs0, r0;
+};
+__device__ __forceinline__ DivConst make_div_const(double b)
+{
+    DivConst c;
+    c.b = b;
+    bool f;
+    c.bs0 = __builtin_amdgcn_div_scale(1.0, b, false, &f);
+    double r = __builtin_amdgcn_rcp(c.bs0);
+    double e = __builtin_fma(-c.bs0, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-c.bs0, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    c.r0 = r;
+    return c;
+}
+__device__ __forceinline__ double div_const(double a, const DivConst &c)
+{
+    bool fd, fn;
+    const double bs = __builtin_amdgcn_div_scale(a, c.b, false, &fd);
+    const double as = __builtin_amdgcn_div_scale(a, c.b, true, &fn);
+    if (__builtin_amdgcn_ballot_w64(bs != c.bs0) != 0ull) return a / c.b;  // wave-uniform
+    const double q0 = as * c.r0;
+    const double rem = __builtin_fma(-bs, q0, as);
+    const double q = __builtin_amdgcn_div_fmas(rem, c.r0, q0, fn);
+    return __builtin_amdgcn_div_fixup(q, c.b, a);
+}
+
 struct BoxArgs {
     int nx, ny, nz;
     int TY, CZ, ytiles;
@@ -1267,6 +1303,7 @@ __global__ __launch_bounds__(kBoxBlock) void sdia_box2_kernel(BoxArgs g, const d
     const long base = (long)(j0 - 2) * nx;  // + k*P + p = global row
     const int tid = threadIdx.x;
     const double c0 = g.c[0], c1 = g.c[1], c2 = g.c[2], c3 = g.c[3], c4 = g.c[4], c5 = g.c[5], c6 = g.c[6], om = g.omega;
+    const DivConst dc = make_div_const(c3);
     for (int i = tid; i < 2 * cells; i += kBoxBlock) box_lds[i] = 0.0;
     bool v0[Q], v1[Q], v2[Q];
     int sidx[Q];
@@ -1326,7 +1363,7 @@ __global__ __launch_bounds__(kBoxBlock) void sdia_box2_kernel(BoxArgs g, const d
                 sum = sum + c5 * X0[s + pitch];
                 sum = sum + c6 * xp[q];
                 const double h = 1.0 * bk[q] + (-1.0) * sum;
-                x1k[q] = xc[q] + om * h / c3;
+                x1k[q] = xc[q] + div_const(om * h, dc);
             }
         }
         const int k2 = k - 1;
@@ -1345,7 +1382,7 @@ __global__ __launch_bounds__(kBoxBlock) void sdia_box2_kernel(BoxArgs g, const d
                     sum = sum + c5 * X1[s + pitch];
                     sum = sum + c6 * x1k[q];
                     const double h = 1.0 * bp[q] + (-1.0) * sum;
-                    y[(long)k2 * P + base + p] = x1c[q] + om * h / c3;
+                    y[(long)k2 * P + base + p] = x1c[q] + div_const(om * h, dc);
                 }
             }
         }
@@ -1362,6 +1399,58 @@ __global__ __launch_bounds__(kBoxBlock) void sdia_box2_kernel(BoxArgs g, const d
             bk[q] = bn[q];
         }
     }
+}
+
+// Residual + restriction (+ the coarse level's zero-guess sweep) on a box-grid level whose aggregates pair a grid point with its
+// neighbour one line (AXIS 1) or one plane (AXIS 2) up, coarse points numbered lexicographically: one thread per aggregate computes
+// both residuals from the seven-point stencil (every access is a unit-stride run along the grid line), adds them in
+// transfer_residual's order and writes b_c and x_c = omega b_c / d_c.  r is never stored, R is never read.  Missing neighbours
+// enter as +0.0 (see sdia_box2_kernel: adding +-0.0 leaves the sum's bits alone).
+__device__ __forceinline__ double box_residual(const BoxArgs &g, const double *__restrict__ x, const double *__restrict__ b, int f, int i, int j,
+                                               int k)
+{
+    const int nx = g.nx, P = g.nx * g.ny;
+    const double xm2 = k > 0 ? x[f - P] : 0.0;
+    const double xm1 = j > 0 ? x[f - nx] : 0.0;
+    const double xm0 = i > 0 ? x[f - 1] : 0.0;
+    const double xc = x[f];
+    const double xp0 = i < nx - 1 ? x[f + 1] : 0.0;
+    const double xp1 = j < g.ny - 1 ? x[f + nx] : 0.0;
+    const double xp2 = k < g.nz - 1 ? x[f + P] : 0.0;
+    const double bi = b[f];
+    double sum = 0.0;
+    sum = sum + g.c[0] * xm2;
+    sum = sum + g.c[1] * xm1;
+    sum = sum + g.c[2] * xm0;
+    sum = sum + g.c[3] * xc;
+    sum = sum + g.c[4] * xp0;
+    sum = sum + g.c[5] * xp1;
+    sum = sum + g.c[6] * xp2;
+    return 1.0 * bi + (-1.0) * sum;
+}
+
+template <int AXIS>
+__global__ __launch_bounds__(kBlock) void box_resid_pair_kernel(BoxArgs g, int nc, int rev, const double *__restrict__ x, const double *__restrict__ b,
+                                                                const double *__restrict__ dc, double dconst, double *__restrict__ bc,
+                                                                double *__restrict__ xc)
+{
+    const int J = blockIdx.x * kBlock + threadIdx.x;
+    if (J >= nc) return;
+    const int nx = g.nx, ny = g.ny;
+    const int cny = AXIS == 1 ? ny / 2 : ny;
+    const int i = J % nx, t = J / nx;
+    const int cj = t % cny, ck = t / cny;
+    const int j = AXIS == 1 ? 2 * cj : cj, k = AXIS == 2 ? 2 * ck : ck;
+    const int f1 = i + nx * (j + ny * k);
+    const int f2 = f1 + (AXIS == 1 ? nx : nx * ny);
+    const int Jout = rev ? nc - 1 - J : J;  // (the matching of some levels numbers its aggregates from the far end of the box)
+    const double dj = dc ? dc[Jout] : dconst;
+    const double r1 = box_residual(g, x, b, f1, i, j, k);
+    const double r2 = box_residual(g, x, b, f2, i, j + (AXIS == 1 ? 1 : 0), k + (AXIS == 2 ? 1 : 0));
+    double s = 0.0 + r1;
+    s = s + r2;
+    bc[Jout] = s;
+    xc[Jout] = g.omega * s / dj;
 }
 
 // ------------------------------------------------------------------ fp32 preconditioner kernels
@@ -1671,6 +1760,26 @@ void launch_box2(const DevCsr &A, const double *x, const double *b, double *y, d
     else if (A.box_q == 3) SPARSH_LAUNCH_BOX(3);
     else SPARSH_LAUNCH_BOX(2);
 #undef SPARSH_LAUNCH_BOX
+}
+
+void launch_box_resid_pair(const DevCsr &A, int axis, const double *x, const double *b, const double *dc, double dconst, double omega,
+                           double *bc, double *xc, hipStream_t st)
+{
+    BoxArgs g;
+    g.nx = A.box_nx;
+    g.ny = A.box_ny;
+    g.nz = A.box_nz;
+    g.TY = g.CZ = g.ytiles = 0;
+    for (int u = 0; u < 7; ++u) g.c[u] = A.sd_tab.cval[u];
+    g.omega = omega;
+    const int nc = A.nrow / 2;
+    if (nc <= 0) return;
+    const dim3 grid((nc + kBlock - 1) / kBlock), block(kBlock);
+    const int rev = axis < 0 ? 1 : 0;
+    if (axis == 1 || axis == -1)
+        hipLaunchKernelGGL(box_resid_pair_kernel<1>, grid, block, 0, st, g, nc, rev, x, b, dc, dconst, bc, xc);
+    else
+        hipLaunchKernelGGL(box_resid_pair_kernel<2>, grid, block, 0, st, g, nc, rev, x, b, dc, dconst, bc, xc);
 }
 
 bool resid_pair_applies(const DevCsr &A, const KernelConfig &c)

@@ -189,6 +189,11 @@ CsrFamily csr_family(const DevCsr &A, const KernelConfig &cfg);
 bool box2_plan(DevCsr &A);
 bool box2_applies(const DevCsr &A, const KernelConfig &cfg);
 void launch_box2(const DevCsr &A, const double *x, const double *b, double *y, double omega, bool finest, hipStream_t st);
+// box-grid level whose aggregates pair a point with its neighbour one line (axis +-1) or one plane (axis +-2) up: residual, restriction and
+// the coarse zero-guess sweep in one launch (dc == nullptr: constant coarse diagonal dconst); axis < 0: aggregates numbered from the far
+// end of the coarse box (J = nc - 1 - lexicographic index)
+void launch_box_resid_pair(const DevCsr &A, int axis, const double *x, const double *b, const double *dc, double dconst, double omega,
+                           double *bc, double *xc, hipStream_t st);
 // OP_RESID_PAIR over the whole of A (a.y = coarse rhs, a.y2 = coarse iterate, a.d = coarse diagonal); applies to operators
 // that run the table kernel under cfg -- resid_pair_applies says whether launch_resid_pair may be called
 bool resid_pair_applies(const DevCsr &A, const KernelConfig &cfg);

@@ -659,6 +659,7 @@ def _line1d(n):
     ("p2d_150", lambda: problems.poisson2d(150)),
     ("line_40001", lambda: _line1d(40001)),  # odd row count: the last aggregate is a single row; levels 0 and 2 pair
     ("line_40000", lambda: _line1d(40000)),
+    ("box_40_36_32", lambda: problems.poisson3d(40, 36, 32)),  # levels 1, 2: aggregates one grid line / one plane apart (box_resid_pair_kernel)
 ])
 def test_paired_restriction_bitwise(name, gen):
     """Levels whose aggregates are the row pairs (2J, 2J+1) run store_residual + transfer_residual + the coarse level's
@@ -673,6 +674,9 @@ def test_paired_restriction_bitwise(name, gen):
     paired = [l for l in range(A.nlevels - 1) if A.level_paired(l)]
     assert 0 in paired, (name, paired)
     assert not A.level_paired(A.nlevels - 2)  # the level above the coarsest keeps the plain restriction (no sweep there)
+    if name == "box_40_36_32":
+        kinds = [A.level_paired(l) for l in range(A.nlevels - 2)]
+        assert kinds[0] == 1 and all(k in (2, 3) for k in kinds[1:3]) and len(set(kinds[1:3])) == 2, kinds  # x pairs, then y and z in some order
     for l in paired:
         nl = A.level_info(l)["nrow"]
         x, b = rng.standard_normal(nl), rng.standard_normal(nl)

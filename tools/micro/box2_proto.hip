@@ -50,6 +50,44 @@ __global__ __launch_bounds__(256) void sweep1_kernel(Box g, const double *__rest
 
 constexpr int kT = 1024;  // threads per workgroup
 
+// a / b for a divisor known before the loop: the compiler's own fp64 division sequence (v_div_scale x2, v_rcp + two Newton steps on the
+// scaled divisor, q0 = a_s r, rem = fma(-b_s, q0, a_s), v_div_fmas, v_div_fixup) with the part that depends on b alone -- the refined
+// reciprocal of the scaled divisor -- computed once.  Where v_div_scale would scale b differently for this a (denormals, exponents
+// ~2^1000 apart: never for residual-sized numbers) the whole wave takes the plain division.  Same instructions on the same operands:
+// bitwise the plain division's result.
+struct DivConst {
+    double b, bs0, r0;
+};
+__device__ __forceinline__ DivConst make_div_const(double b)
+{
+    DivConst c;
+    c.b = b;
+    bool f;
+    c.bs0 = __builtin_amdgcn_div_scale(1.0, b, false, &f);
+    double r = __builtin_amdgcn_rcp(c.bs0);
+    double e = __builtin_fma(-c.bs0, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-c.bs0, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    c.r0 = r;
+    return c;
+}
+__device__ __forceinline__ double div_const(double a, const DivConst &c)
+{
+#ifdef FASTDIV
+    bool fd, fn;
+    const double bs = __builtin_amdgcn_div_scale(a, c.b, false, &fd);
+    const double as = __builtin_amdgcn_div_scale(a, c.b, true, &fn);
+    if (__builtin_amdgcn_ballot_w64(bs != c.bs0) != 0ull) return a / c.b;
+    const double q0 = as * c.r0;
+    const double rem = __builtin_fma(-bs, q0, as);
+    const double q = __builtin_amdgcn_div_fmas(rem, c.r0, q0, fn);
+    return __builtin_amdgcn_div_fixup(q, c.b, a);
+#else
+    return a / c.b;
+#endif
+}
+
 // region of a workgroup in a plane: lines j0-2 .. j0+TY+1 (TY+4 lines, contiguous in memory), local index p = tid + kT*q
 // x0 is needed on all of them, the first sweep runs on lines 1 .. TY+2 of the region, the second on lines 2 .. TY+1.
 // Neighbours that do not exist are read as +0.0 (zero pad cell between the lines in LDS, zero lines / planes outside the grid):
@@ -81,6 +119,7 @@ __global__ __launch_bounds__(kT) void box2_kernel(Box g, int TY, int CZ, int yti
     const long base = (long)(j0 - 2) * nx;  // + k*P + p
     const int tid = threadIdx.x;
     const double c0 = g.c[0], c1 = g.c[1], c2 = g.c[2], c3 = g.c[3], c4 = g.c[4], c5 = g.c[5], c6 = g.c[6], om = g.omega;
+    const DivConst dc = make_div_const(c3);
     for (int i = tid; i < 2 * cells; i += kT) lds[i] = 0.0;
     bool v0[Q], v1[Q], v2[Q];
     int sidx[Q];
@@ -140,7 +179,7 @@ __global__ __launch_bounds__(kT) void box2_kernel(Box g, int TY, int CZ, int yti
                 sum = sum + c5 * X0[s + pitch];
                 sum = sum + c6 * xp[q];
                 const double h = 1.0 * bk[q] + (-1.0) * sum;
-                x1k[q] = xc[q] + om * h / c3;
+                x1k[q] = xc[q] + div_const(om * h, dc);
             }
         }
         const int k2 = k - 1;
@@ -159,7 +198,7 @@ __global__ __launch_bounds__(kT) void box2_kernel(Box g, int TY, int CZ, int yti
                     sum = sum + c5 * X1[s + pitch];
                     sum = sum + c6 * x1k[q];
                     const double h = 1.0 * bp[q] + (-1.0) * sum;
-                    y[(long)k2 * P + base + p] = x1c[q] + om * h / c3;
+                    y[(long)k2 * P + base + p] = x1c[q] + div_const(om * h, dc);
                 }
             }
         }
