@@ -199,6 +199,17 @@ int sparsh_set_constant_diagonal(sparsh_handle h, int enable);
  * thread, lines per tile, planes per chunk}; the setup's timings of two single sweeps / one double sweep in us (0: not timed).
  * Any output pointer may be NULL. */
 int sparsh_set_double_sweep(sparsh_handle h, int mode);
+/* The launches of a box-grid level that carry an epilogue of their own -- A p with the p.Ap dot (Solver_PCG's mv + cublasDdot,
+ * src/AMG_main_solvers.cu), the last post-sweep with the z.r dot or with the prolongation, the residual with the pair restriction --
+ * through the same plane-marching scheme with one stencil application per launch (sdia_box1_kernel): x of the current plane in LDS,
+ * its neighbours in z in registers, so every x is read once instead of being gathered by seven rows.  The vectors it stores are
+ * bitwise the table kernel's; its fused dot products are summed per workgroup of this kernel rather than per 256 rows -- same
+ * terms, another order of additions, i.e. a difference in the last bits of a reduction (within the 1e-12 the parity tests hold
+ * reductions to).  mode as for the double sweep (0 / 1 timed at setup, default / 2 forced).  sparsh_level_marching_ops: on, plan =
+ * {points per thread, lines per tile, planes per chunk}, the setup's timing of the last post-sweep + dot through the table kernel
+ * and through this one (us, 0: not timed). */
+int sparsh_set_marching_ops(sparsh_handle h, int mode);
+int sparsh_level_marching_ops(sparsh_handle h, int level, int *on, int *plan, double *table_us, double *marching_us);
 int sparsh_level_double_sweep(sparsh_handle h, int level, int *on, int *dims, int *plan, double *single_us, double *double_us);
 int sparsh_level_constant_diagonal(sparsh_handle h, int level, int *is_const, double *value);
 int sparsh_level_prolong_fused(sparsh_handle h, int level, int *fused);

@@ -95,6 +95,8 @@ def _load():
         "sparsh_set_fused_prolongation": (C.c_int, [H, C.c_int]),
         "sparsh_set_constant_diagonal": (C.c_int, [H, C.c_int]),
         "sparsh_set_double_sweep": (C.c_int, [H, C.c_int]),
+        "sparsh_set_marching_ops": (C.c_int, [H, C.c_int]),
+        "sparsh_level_marching_ops": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "sparsh_level_double_sweep": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                                   C.POINTER(C.c_double)]),
         "sparsh_level_constant_diagonal": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
@@ -351,6 +353,20 @@ class sp_matrix_mg:
         _check(lib.sparsh_level_double_sweep(self._h, int(level), C.byref(on), dims, plan, C.byref(t1), C.byref(t2)))
         return {"on": bool(on.value), "grid": list(dims), "points_per_thread": plan[0], "lines_per_tile": plan[1], "planes_per_chunk": plan[2],
                 "two_single_sweeps_us": round(t1.value, 2), "double_sweep_us": round(t2.value, 2)}
+
+    def set_marching_ops(self, mode=1):
+        """SpMV + dot, last post-sweep (+ dot / + prolongation), residual + pair restriction of box-grid levels through the plane-marching
+        kernel: 0 never, 1 where the setup times it faster (default), 2 wherever a plan exists.  Read by setup."""
+        _check(lib.sparsh_set_marching_ops(self._h, int(mode)))
+        return self
+
+    def level_marching_ops(self, level):
+        on = C.c_int(0)
+        plan = (C.c_int * 3)()
+        t1, t2 = C.c_double(0.0), C.c_double(0.0)
+        _check(lib.sparsh_level_marching_ops(self._h, int(level), C.byref(on), plan, C.byref(t1), C.byref(t2)))
+        return {"on": bool(on.value), "points_per_thread": plan[0], "lines_per_tile": plan[1], "planes_per_chunk": plan[2],
+                "table_kernel_us": round(t1.value, 2), "marching_kernel_us": round(t2.value, 2)}
 
     def set_constant_diagonal(self, enable=True):
         """Levels with one constant diagonal: the zero-guess sweeps take it as an argument instead of streaming diag[]."""

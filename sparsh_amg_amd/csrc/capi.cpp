@@ -424,7 +424,7 @@ int sparsh_level_double_sweep(sparsh_handle h, int level, int *on, int *dims, in
     REQUIRE_READY(h);
     REQUIRE_LEVEL(h, level);
     const DevLevel &L = h->eng->level(level);
-    if (on) *on = !h->eng->distributed() && box2_applies(L.A, h->eng->kernel_cfg()) ? 1 : 0;
+    if (on) *on = (!h->eng->distributed() || L.replicated) && box2_applies(L.A, h->eng->kernel_cfg()) ? 1 : 0;
     if (dims) {
         dims[0] = L.A.box_nx;
         dims[1] = L.A.box_ny;
@@ -437,6 +437,31 @@ int sparsh_level_double_sweep(sparsh_handle h, int level, int *on, int *dims, in
     }
     if (single_us) *single_us = L.box_single_us;
     if (double_us) *double_us = L.box_double_us;
+    return SPARSH_OK;
+}
+
+int sparsh_set_marching_ops(sparsh_handle h, int mode)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    if (mode < 0 || mode > 2) return fail(SPARSH_EINVAL, "mode must be 0 (never), 1 (where the setup measures it faster) or 2 (wherever the level is a box grid with a plan)");
+    h->eng->kernel_cfg().box1 = mode;
+    h->eng->config_changed();
+    return SPARSH_OK;
+}
+
+int sparsh_level_marching_ops(sparsh_handle h, int level, int *on, int *plan, double *table_us, double *marching_us)
+{
+    REQUIRE_READY(h);
+    REQUIRE_LEVEL(h, level);
+    const DevLevel &L = h->eng->level(level);
+    if (on) *on = (!h->eng->distributed() || L.replicated) && box1_applies(L.A, h->eng->kernel_cfg()) ? 1 : 0;
+    if (plan) {
+        plan[0] = L.A.box1_q;
+        plan[1] = L.A.box1_ty;
+        plan[2] = L.A.box1_cz;
+    }
+    if (table_us) *table_us = L.box1_table_us;
+    if (marching_us) *marching_us = L.box1_us;
     return SPARSH_OK;
 }
 

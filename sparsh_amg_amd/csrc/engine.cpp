@@ -385,6 +385,7 @@ bool upload_sdia(Engine &E, const HostCsr &A, DevCsr &D)
                     D.box_ny = ny;
                     D.box_nz = nz;
                     box2_plan(D);
+                    box1_plan(D);
                 }
             }
         }
@@ -643,13 +644,15 @@ void Engine::tune_box2()
 {
     for (size_t l = 0; l + 1 < lev_.size(); ++l) {
         DevLevel &L = lev_[l];
-        L.A.box_on = false;
-        L.box_single_us = L.box_double_us = 0.0;
-        if (cfg_.box2 == 0 || L.A.box_q <= 0 || dist_ || L.deep || csr_family(L.A, cfg_) != FAM_SDIA_TAB) continue;
-        if (cfg_.box2 >= 2) {
-            L.A.box_on = true;
-            continue;
-        }
+        L.A.box_on = L.A.box1_on = false;
+        L.box_single_us = L.box_double_us = L.box1_table_us = L.box1_us = 0.0;
+        // (several GPUs: the replicated levels are whole levels on every rank and take the same path; ranks may decide differently,
+        // the results are the same bits either way)
+        if (L.A.box_q <= 0 || (dist_ && !L.replicated) || L.deep || csr_family(L.A, cfg_) != FAM_SDIA_TAB) continue;
+        if (cfg_.box2 >= 2) L.A.box_on = true;
+        if (cfg_.box1 >= 2) L.A.box1_on = L.A.box1_q > 0;
+        const bool time2 = cfg_.box2 == 1, time1 = cfg_.box1 == 1 && L.A.box1_q > 0;
+        if (!(time1 || time2)) continue;
         if (L.n < 400000) continue;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) continue;
@@ -678,9 +681,34 @@ void Engine::tune_box2()
             (void)hipEventElapsedTime(&ms, e0, e1);
             return (double)ms * 1e3 / 4.0;  // per pair of sweeps
         };
-        L.box_single_us = timed(false);
-        L.box_double_us = timed(true);
-        L.A.box_on = L.box_double_us < 0.97 * L.box_single_us;
+        if (time2) {
+            L.box_single_us = timed(false);
+            L.box_double_us = timed(true);
+            L.A.box_on = L.box_double_us < 0.97 * L.box_single_us;
+        }
+        if (time1) {
+            // the launches with an epilogue: the last post-sweep with its dot through the table kernel against the plane-marching kernel
+            auto timed1 = [&](bool marching) -> double {
+                double *p = L.x, *q = L.x2;
+                for (int it = 0; it < 8; ++it) {
+                    if (it == 2) (void)hipEventRecord(e0, st_);
+                    a.x = p;
+                    a.y = q;
+                    a.partial = part0_;
+                    if (marching) launch_box1(L.A, 1, a, L.fine, st_);
+                    else launch_csr(L.A, OP_JACOBI_DOT, a, L.fine, st_, cfg_);
+                    std::swap(p, q);
+                }
+                (void)hipEventRecord(e1, st_);
+                if (hipEventSynchronize(e1) != hipSuccess) return 1e30;
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                return (double)ms * 1e3 / 6.0;
+            };
+            L.box1_table_us = timed1(false);
+            L.box1_us = timed1(true);
+            L.A.box1_on = L.box1_us < 0.97 * L.box1_table_us;
+        }
         (void)hipMemsetAsync(L.x, 0, (size_t)L.n * 8, st_);
         (void)hipMemsetAsync(L.x2, 0, (size_t)L.n * 8, st_);
         (void)hipMemsetAsync(L.r, 0, (size_t)L.n * 8, st_);
@@ -1188,7 +1216,7 @@ int Engine::setup(const sparsh_params &p)
             if (l + 1 < nl) {
                 if (!upload_csr(*this, h.P, d.P, false) || !upload_csr(*this, h.R, d.R, false)) return SPARSH_ENODEV;
                 d.P_is_aggregation = h.P_is_aggregation;
-                if (h.P_is_aggregation && !dist_) {
+                if (h.P_is_aggregation) {  // (a replicated level: the next one is replicated too)
                     // HEM pairs neighbours along the first grid line on most levels of a lexicographically ordered grid:
                     // aggregate J = rows (2J, 2J+1) (a last single row when n is odd), listed in that order by R
                     const int n = h.A.nrow, nc = h.R.nrow;
@@ -1363,7 +1391,7 @@ int Engine::setup(const sparsh_params &p)
     place_tried = 0;
     place_best_us = place_worst_us = place_first_us = 0.0;
     phase("coarsest-level factorisation + workspace");
-    if (G == 1) tune_box2();
+    tune_box2();
     if (G == 1 && cfg_.place_search) tune_placement();
     phase("placement search");
     f32_ready_ = false;
@@ -1554,6 +1582,11 @@ int Engine::apply_A(DevLevel &L, CsrOp op, CsrArgs a)
         if (!deep_exchange(L, 0, xin)) return 0;
         return launch_prefix(L, L.n, op, a);
     }
+    if ((op == OP_SPMV_DOT || op == OP_JACOBI_DOT || op == OP_JACOBI_PROLONG) && (!dist_ || L.replicated) && !a.slice_list &&
+        box1_applies(L.A, cfg_)) {
+        // box-grid level: the launches that carry an epilogue run the plane-marching kernel (every x read once)
+        return launch_box1(L.A, op == OP_SPMV_DOT ? 0 : (op == OP_JACOBI_DOT ? 1 : 3), a, L.fine, st_);
+    }
     const CsrFamily fam = csr_family(L.A, cfg_);
     const bool sliced = fam == FAM_SDIA || fam == FAM_SDIA_TAB || fam == FAM_SELL;
     if (!(dist_ && overlap_ && !L.replicated && sliced && L.A.nint > 0 && L.A.nbnd > 0 && st2_)) {
@@ -1627,6 +1660,10 @@ void Engine::op_residual_restrict(int l, const double *b, const double *x, doubl
     a.d = diag_stream(lev_[l + 1]);
     a.dconst = lev_[l + 1].diag_const;
     a.omega = prm_.omega;
+    if (box1_applies(lev_[l].A, cfg_) && lev_[l].A.box_nx % 2 == 0) {  // (an even line length: every row pair lies within one line)
+        launch_box1(lev_[l].A, 2, a, lev_[l].fine, st_);
+        return;
+    }
     launch_resid_pair(lev_[l].A, a, lev_[l].fine, st_, cfg_);
 }
 
@@ -1754,7 +1791,7 @@ void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, doubl
     const bool timed = prof.enabled && &L == &lev_[0] && k < sweeps && prof.used + 2 <= prof.ev.size();
     if (timed) HIPCHK(hipEventRecord(prof.ev[prof.used], st_));
     int in_run = 0;
-    const bool pairs = !dist_ && box2_applies(L.A, cfg_);
+    const bool pairs = (!dist_ || L.replicated) && box2_applies(L.A, cfg_);
     bool timed_open = timed;
     const bool special_last = dot_partial || prolong_to;  // the last sweep carries an epilogue of its own
     for (; k < sweeps; ++k) {

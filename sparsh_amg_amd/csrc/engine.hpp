@@ -40,6 +40,7 @@ struct DevLevel {
                                    // one plane (2) up: residual + restriction without r and R (box_resid_pair_kernel)
     bool pair_aggregates = false;  // aggregate J = fine rows (2J, 2J+1) in R's stored order: residual + restriction fuse (OP_RESID_PAIR)
     double *diag = nullptr;
+    double box1_table_us = 0.0, box1_us = 0.0;        // setup timing of the last post-sweep + dot: table kernel / plane-marching kernel
     double box_single_us = 0.0, box_double_us = 0.0;  // setup timing of two single sweeps / one double sweep (tune_box2), 0 = not timed
     bool diag_is_const = false;  // every (own) row has the same diagonal entry, diag_const
     double diag_const = 0.0;
@@ -114,15 +115,16 @@ public:
     // whether level l's last post-sweep also prolongates into level l - 1 (OP_JACOBI_PROLONG)
     bool level_prolong_fused(int l) const
     {
-        if (l < 1 || l + 1 >= (int)lev_.size() || dist_ || !cfg_.fuse_prolong || prm_.sweeps < 1 || prm_.precond_fp32) return false;
+        if (l < 1 || l + 1 >= (int)lev_.size() || !cfg_.fuse_prolong || prm_.sweeps < 1 || prm_.precond_fp32) return false;
         const DevLevel &F = lev_[l - 1];
+        if (dist_ && !F.replicated) return false;  // several GPUs: between replicated levels only
         return F.P_is_aggregation && !F.deep && (F.pair_aggregates || F.members) && F.R.nrow == lev_[l].n;
     }
     // whether level l's residual, restriction and the next level's zero-guess sweep run as one launch (OP_RESID_PAIR)
     // 0 no; 1 aggregates = row pairs (2J, 2J+1): OP_RESID_PAIR of the table kernel; 2 / 3 box-grid level paired along y / z
     int level_paired(int l) const
     {
-        if (!(l + 2 < (int)lev_.size() && prm_.sweeps > 0 && !dist_ && cfg_.pair_restrict)) return 0;
+        if (!(l + 2 < (int)lev_.size() && prm_.sweeps > 0 && (!dist_ || lev_[l].replicated) && cfg_.pair_restrict)) return 0;
         if (lev_[l].pair_aggregates && resid_pair_applies(lev_[l].A, cfg_)) return 1;
         if (lev_[l].pair_axis != 0 && lev_[l].A.box_nx > 0 && csr_family(lev_[l].A, cfg_) == FAM_SDIA_TAB) return 1 + std::abs(lev_[l].pair_axis);
         return 0;

@@ -1401,6 +1401,177 @@ __global__ __launch_bounds__(kBoxBlock) void sdia_box2_kernel(BoxArgs g, const d
     }
 }
 
+// One stencil application per launch on the same marching-plane scheme (the launches of a box-grid level that carry an epilogue of their
+// own: SpMV with the p.Ap dot, the last post-sweep with the z.r dot or with the prolongation, the residual with the pair restriction).
+// x of plane k in LDS for the in-plane neighbours, planes k -+ 1 at the own point in registers: every x is read once (+ one halo line per
+// side of the tile and one halo plane per end of the chunk) instead of being gathered by seven rows through L1 / L2; nothing is
+// recomputed.  Products in table order, the table kernel's epilogue expressions: the stored vectors are bitwise the table kernel's.  The
+// fused dot products are summed per workgroup of this kernel (one partial each) instead of per 256 rows: same terms, another order of
+// additions -- the one place where the two paths differ, in the last bits of a reduction (reductions are held to 1e-12, section 2).
+enum BoxEpi : int { BOX_SPMV_DOT = 0, BOX_JACOBI_DOT = 1, BOX_RESID_PAIRX = 2, BOX_JACOBI_PROLONG = 3 };
+
+struct Box1Args {
+    const double *x, *b;     // input vector, right-hand side (not read by SPMV_DOT)
+    double *y;               // SPMV_DOT: A x; JACOBI_DOT: the sweep's result; RESID_PAIRX: coarse right-hand side
+    double *y2;              // RESID_PAIRX: coarse zero-guess sweep; JACOBI_PROLONG: the finer level's iterate
+    const double *dc;        // RESID_PAIRX: coarse diagonal (nullptr: dconst)
+    double dconst;
+    const int *members;      // JACOBI_PROLONG: (first, second) fine rows per row; nullptr = rows (2i, 2i+1)
+    int nfine;
+    double *partial;         // one per workgroup (the reducing epilogues)
+};
+
+template <int Q, int EPI, int TAG>
+__global__ __launch_bounds__(kBoxBlock) void sdia_box1_kernel(BoxArgs g, Box1Args a)
+{
+    extern __shared__ double box_lds[];
+    __shared__ double red[kBoxBlock / 64];
+    const int nx = g.nx, ny = g.ny, nz = g.nz, P = nx * ny, TY = g.TY;
+    const int R0 = (TY + 2) * nx;
+    const int pitch = nx + 1;
+    const int cells = (TY + 2) * pitch + 1;
+    double *X0 = box_lds;
+    int wg = blockIdx.x;
+    {
+        const int nwg = gridDim.x, per = nwg / 8, rem = nwg % 8;
+        const int c = wg % 8, r = wg / 8;
+        wg = c * per + min(c, rem) + r;
+    }
+    const int tile = wg % g.ytiles, zc = wg / g.ytiles;
+    const int j0 = tile * TY;
+    const int z0 = zc * g.CZ, z1 = min(z0 + g.CZ, nz);
+    const long base = (long)(j0 - 1) * nx;
+    const int tid = threadIdx.x;
+    const double c0 = g.c[0], c1 = g.c[1], c2 = g.c[2], c3 = g.c[3], c4 = g.c[4], c5 = g.c[5], c6 = g.c[6], om = g.omega;
+    constexpr bool kNeedsB = EPI != BOX_SPMV_DOT;
+    constexpr bool kDivides = EPI == BOX_JACOBI_DOT || EPI == BOX_JACOBI_PROLONG;
+    DivConst dc3 = {1.0, 1.0, 1.0};
+    if constexpr (kDivides) dc3 = make_div_const(c3);
+    for (int i = tid; i < cells; i += kBoxBlock) X0[i] = 0.0;
+    bool v0[Q], v1[Q];
+    int sidx[Q];
+    double xm[Q], xc[Q], xp[Q], bk[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int p = tid + kBoxBlock * q;
+        const int lr = p / nx;
+        const int jr = j0 - 1 + lr;
+        sidx[q] = p + lr + 1;
+        v0[q] = p < R0 && jr >= 0 && jr < ny;
+        v1[q] = v0[q] && lr >= 1 && lr <= TY;
+        xm[q] = xc[q] = xp[q] = bk[q] = 0.0;
+        if (v0[q]) {
+            if (z0 >= 1) xm[q] = a.x[(long)(z0 - 1) * P + base + p];
+            xc[q] = a.x[(long)z0 * P + base + p];
+            if (z0 + 1 < nz) xp[q] = a.x[(long)(z0 + 1) * P + base + p];
+        }
+        if constexpr (kNeedsB) {
+            if (v1[q]) bk[q] = a.b[(long)z0 * P + base + p];
+        }
+    }
+    __syncthreads();
+    double acc = 0.0;
+    for (int k = z0; k < z1; ++k) {  // every thread of the workgroup runs the same z1 - z0 steps
+        double xn[Q], bn[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int p = tid + kBoxBlock * q;
+            xn[q] = 0.0;
+            bn[q] = 0.0;
+            if (k + 1 < z1) {
+                if (v0[q] && k + 2 < nz) xn[q] = a.x[(long)(k + 2) * P + base + p];
+                if constexpr (kNeedsB) {
+                    if (v1[q]) bn[q] = a.b[(long)(k + 1) * P + base + p];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+            if (v0[q]) X0[sidx[q]] = xc[q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int p = tid + kBoxBlock * q;
+            const int s = sidx[q];
+            const long row = (long)k * P + base + p;
+            double sum = 0.0;
+            if (v1[q]) {
+                sum = sum + c0 * xm[q];
+                sum = sum + c1 * X0[s - pitch];
+                sum = sum + c2 * X0[s - 1];
+                sum = sum + c3 * xc[q];
+                sum = sum + c4 * X0[s + 1];
+                sum = sum + c5 * X0[s + pitch];
+                sum = sum + c6 * xp[q];
+            }
+            if constexpr (EPI == BOX_SPMV_DOT) {
+                if (v1[q]) {
+                    a.y[row] = sum;
+                    acc += xc[q] * sum;
+                }
+            } else if constexpr (EPI == BOX_JACOBI_DOT) {
+                if (v1[q]) {
+                    const double h = 1.0 * bk[q] + (-1.0) * sum;
+                    const double xnew = xc[q] + div_const(om * h, dc3);
+                    a.y[row] = xnew;
+                    acc += xnew * bk[q];
+                }
+            } else if constexpr (EPI == BOX_JACOBI_PROLONG) {
+                if (v1[q]) {
+                    const double h = 1.0 * bk[q] + (-1.0) * sum;
+                    const double xnew = xc[q] + div_const(om * h, dc3);
+                    if (a.members) {
+                        const i2v m = *reinterpret_cast<const i2v *>(a.members + 2 * row);
+                        a.y2[m.x] = 1.0 * xnew + a.y2[m.x];
+                        if (m.y >= 0) a.y2[m.y] = 1.0 * xnew + a.y2[m.y];
+                    } else {
+                        const long f = 2 * row;
+                        if (f + 1 < a.nfine) {
+                            d2v *pp = reinterpret_cast<d2v *>(a.y2 + f);
+                            d2v v = *pp;
+                            v.x = 1.0 * xnew + v.x;
+                            v.y = 1.0 * xnew + v.y;
+                            *pp = v;
+                        } else {
+                            a.y2[f] = 1.0 * xnew + a.y2[f];
+                        }
+                    }
+                }
+            } else {  // BOX_RESID_PAIRX: nx is even, so a line starts on an even row and lane parity = row parity
+                const double ri = v1[q] ? 1.0 * bk[q] + (-1.0) * sum : 0.0;
+                const double rn = lane_from_above(ri, 0.0);
+                if (v1[q] && !(tid & 1)) {
+                    const long J = row >> 1;
+                    double bc = 0.0 + ri;
+                    bc = bc + rn;
+                    a.y[J] = bc;
+                    a.y2[J] = om * bc / (a.dc ? a.dc[J] : a.dconst);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            xm[q] = xc[q];
+            xc[q] = xp[q];
+            xp[q] = xn[q];
+            bk[q] = bn[q];
+        }
+    }
+    if constexpr (EPI == BOX_SPMV_DOT || EPI == BOX_JACOBI_DOT) {
+        acc = wave_sum(acc);
+        const int lane = tid & 63, w = tid >> 6;
+        if (lane == 0) red[w] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < kBoxBlock / 64; ++q) t += red[q];
+            a.partial[blockIdx.x] = t;
+        }
+    }
+}
+
 // Residual + restriction (+ the coarse level's zero-guess sweep) on a box-grid level whose aggregates pair a grid point with its
 // neighbour one line (AXIS 1) or one plane (AXIS 2) up, coarse points numbered lexicographically: one thread per aggregate computes
 // both residuals from the seven-point stencil (every access is a unit-stride run along the grid line), adds them in
@@ -1730,6 +1901,86 @@ bool box2_plan(DevCsr &A)
         }
     }
     return A.box_q > 0;
+}
+
+// plan of the single-stage kernel: region = TY + 2 lines, one LDS plane, nothing recomputed; a workgroup's time ~ (CZ + 1) steps x Q points
+bool box1_plan(DevCsr &A)
+{
+    A.box1_q = A.box1_ty = A.box1_cz = 0;
+    const int nx = A.box_nx, ny = A.box_ny, nz = A.box_nz;
+    if (nx < 2 || ny < 1 || nz < 1) return false;
+    long best = -1;
+    for (int Q = 2; Q <= 4; ++Q) {
+        int TY = std::min(ny, Q * kBoxBlock / nx - 2);
+        while (TY >= 1 && ((size_t)(TY + 2) * (nx + 1) + 1) * sizeof(double) > 65536) --TY;
+        if (TY < 1) continue;
+        const int ytiles = (ny + TY - 1) / TY;
+        for (int zch = 1; zch <= nz; ++zch) {
+            const int CZ = (nz + zch - 1) / zch;
+            const int chunks = (nz + CZ - 1) / CZ;
+            const long wgs = (long)ytiles * chunks, rounds = (wgs + 255) / 256;
+            const long cost = rounds * (CZ + 1) * Q;
+            if (best < 0 || cost < best) {
+                best = cost;
+                A.box1_q = Q;
+                A.box1_ty = TY;
+                A.box1_cz = CZ;
+            }
+        }
+    }
+    return A.box1_q > 0;
+}
+
+bool box1_applies(const DevCsr &A, const KernelConfig &c)
+{
+    return c.box1 != 0 && A.box1_on && A.box1_q > 0 && csr_family(A, c) == FAM_SDIA_TAB;
+}
+
+int launch_box1(const DevCsr &A, int epi, const CsrArgs &a, bool finest, hipStream_t st)
+{
+    BoxArgs g;
+    g.nx = A.box_nx;
+    g.ny = A.box_ny;
+    g.nz = A.box_nz;
+    g.TY = A.box1_ty;
+    g.CZ = A.box1_cz;
+    g.ytiles = (g.ny + g.TY - 1) / g.TY;
+    for (int u = 0; u < 7; ++u) g.c[u] = A.sd_tab.cval[u];
+    g.omega = a.omega;
+    Box1Args b;
+    b.x = a.x;
+    b.b = a.b;
+    b.y = a.y;
+    b.y2 = a.y2;
+    b.dc = a.d;
+    b.dconst = a.dconst;
+    b.members = a.members;
+    b.nfine = a.nfine;
+    b.partial = a.partial ? a.partial + a.partial_off : nullptr;
+    const int chunks = (g.nz + g.CZ - 1) / g.CZ;
+    const int nwg = g.ytiles * chunks;
+    const dim3 grid(nwg), block(kBoxBlock);
+    const size_t lds = ((size_t)(g.TY + 2) * (g.nx + 1) + 1) * sizeof(double);
+#define SPARSH_LAUNCH_BOX1(Q_, E_)                                                                  \
+    do {                                                                                            \
+        if (finest) hipLaunchKernelGGL((sdia_box1_kernel<Q_, E_, 1>), grid, block, lds, st, g, b);  \
+        else hipLaunchKernelGGL((sdia_box1_kernel<Q_, E_, 0>), grid, block, lds, st, g, b);         \
+    } while (0)
+#define SPARSH_LAUNCH_BOX1_Q(E_)                      \
+    do {                                              \
+        if (A.box1_q == 4) SPARSH_LAUNCH_BOX1(4, E_); \
+        else if (A.box1_q == 3) SPARSH_LAUNCH_BOX1(3, E_); \
+        else SPARSH_LAUNCH_BOX1(2, E_);               \
+    } while (0)
+    switch (epi) {
+    case BOX_SPMV_DOT: SPARSH_LAUNCH_BOX1_Q(BOX_SPMV_DOT); break;
+    case BOX_JACOBI_DOT: SPARSH_LAUNCH_BOX1_Q(BOX_JACOBI_DOT); break;
+    case BOX_RESID_PAIRX: SPARSH_LAUNCH_BOX1_Q(BOX_RESID_PAIRX); break;
+    default: SPARSH_LAUNCH_BOX1_Q(BOX_JACOBI_PROLONG); break;
+    }
+#undef SPARSH_LAUNCH_BOX1_Q
+#undef SPARSH_LAUNCH_BOX1
+    return nwg;
 }
 
 bool box2_applies(const DevCsr &A, const KernelConfig &c)

@@ -80,6 +80,9 @@ struct DevCsr {
     int box_nx = 0, box_ny = 0, box_nz = 0;
     int box_q = 0, box_ty = 0, box_cz = 0;
     bool box_on = false;
+    // the same for the single-stage kernel of the launches that carry an epilogue (sdia_box1_kernel): plan and the setup's verdict
+    int box1_q = 0, box1_ty = 0, box1_cz = 0;
+    bool box1_on = false;
     // rank-local blocks: slices whose rows touch no halo column (interior) / some (boundary)
     int *int_list = nullptr, *bnd_list = nullptr;
     int nint = 0, nbnd = 0;
@@ -107,6 +110,9 @@ struct KernelConfig {
     bool fuse_cg_zero = true; // PCG: the cg_update kernel also writes the V-cycle's zero-guess sweep of level 0
     int alt_dir = 1;          // consecutive sweeps of a smoothing leg walk the level in alternating directions (CsrArgs::reverse):
                               // 0 never, 1 where a sweep streams more than 640 MB (2.5x the Infinity Cache), 2 always
+    int box1 = 1;              // box-grid levels: the launches with an epilogue of their own (SpMV + dot, last post-sweep + dot / + prolongation,
+                               // residual + pair restriction) through the plane-marching kernel (sdia_box1_kernel): 0 never, 1 where the setup
+                               // measured it faster than the table kernel (levels of >= 400 000 rows), 2 wherever a plan exists
     int box2 = 1;              // box-grid levels (DevCsr::box_nx): two Jacobi sweeps per launch (sdia_box2_kernel): 0 never, 1 where the
                                // setup measured it faster than two single sweeps (levels of >= 400 000 rows), 2 wherever a plan exists
     bool const_diag = true;    // levels whose diagonal is one constant: the vector kernels that divide by it (zero-guess sweeps fused
@@ -194,6 +200,12 @@ void launch_box2(const DevCsr &A, const double *x, const double *b, double *y, d
 // end of the coarse box (J = nc - 1 - lexicographic index)
 void launch_box_resid_pair(const DevCsr &A, int axis, const double *x, const double *b, const double *dc, double dconst, double omega,
                            double *bc, double *xc, hipStream_t st);
+// Single-stage plane-marching kernel on a box-grid level (sdia_box1_kernel); epi: 0 y = A x + partial x.Ax, 1 Jacobi sweep into y + partial
+// y.b, 2 residual + pair restriction (aggregates = row pairs; y = coarse rhs, y2 = coarse zero-guess sweep, d / dconst = coarse diagonal),
+// 3 Jacobi sweep added to the finer iterate y2 (members / nfine as OP_JACOBI_PROLONG).  Returns the number of partial sums written.
+bool box1_plan(DevCsr &A);
+bool box1_applies(const DevCsr &A, const KernelConfig &cfg);
+int launch_box1(const DevCsr &A, int epi, const CsrArgs &a, bool finest, hipStream_t st);
 // OP_RESID_PAIR over the whole of A (a.y = coarse rhs, a.y2 = coarse iterate, a.d = coarse diagonal); applies to operators
 // that run the table kernel under cfg -- resid_pair_applies says whether launch_resid_pair may be called
 bool resid_pair_applies(const DevCsr &A, const KernelConfig &cfg);

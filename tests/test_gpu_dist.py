@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 QUIET = dict(print_setup=0, print_solve=0)
 
 
-def run_ranks(rp, ci, v, b, G, method, overlap=False, deep=None, kcfg=None, idx16=None, **kw):
+def run_ranks(rp, ci, v, b, G, method, overlap=False, deep=None, kcfg=None, idx16=None, double_sweep=None, **kw):
     group = sa.comm_group_create(G)
     out = [None] * G
     errs = []
@@ -26,6 +26,8 @@ def run_ranks(rp, ci, v, b, G, method, overlap=False, deep=None, kcfg=None, idx1
             A.comm_init_group(group, r)
             if idx16 is not None:
                 A.set_index_compression(idx16)
+            if double_sweep is not None:
+                A.set_double_sweep(double_sweep)
             if kcfg is not None:
                 A.set_kernel_config(*kcfg)
             if deep is not None or overlap:
@@ -194,6 +196,33 @@ def test_everything_replicated_small_problem():
     res = run_ranks(rp, ci, v, b, 2, "pcg")  # default replicate_rows > n: every rank solves it all
     assert all(r[2] for r in res) and all(r[1] - r[0] == n for r in res)
     assert np.array_equal(res[0][3], res[1][3])
+
+
+@pytest.mark.parametrize("G", [2, 3])
+def test_replicated_levels_take_the_fused_single_gpu_paths(G):
+    """Several GPUs: the replicated coarse levels are whole levels on every rank, so they run the double sweeps, the fused
+    residual + restriction and the prolongating last post-sweep exactly as one GPU does.  Two partitioned levels, four replicated
+    ones (double sweep forced on); histories against the single-GPU run of the same configuration."""
+    rp, ci, v = problems.poisson3d(48, 40, 36)
+    n = len(rp) - 1
+    b = np.random.default_rng(5).standard_normal(n)
+    A1 = sa.sp_matrix_mg(rp, ci, v).set_double_sweep(2).setup(sa.default_params(**QUIET))
+    assert A1.nlevels >= 5 and A1.level_double_sweep(2)["on"] and A1.level_paired(2) and A1.level_prolong_fused(3)
+    for method in ("pcg", "amg"):
+        x1 = np.zeros(n)
+        h1, rc1 = A1.solve(method, b, x1)
+        res = run_ranks(rp, ci, v, b, G, method, double_sweep=2, replicate_rows=20000)
+        reps = [rep for (lo, hi, rep) in res[0][6]]
+        assert reps[:2] == [False, False] and all(reps[2:]), reps
+        x = np.concatenate([r[3] for r in sorted(res, key=lambda t: t[0])])
+        for r in res:
+            assert r[5] == rc1 and np.array_equal(r[4], res[0][4])
+        h = res[0][4]
+        assert len(h) == len(h1)
+        tol = np.where(h1 >= 1e-6 * h1[0], 1e-8, 1e-4)
+        assert np.all(np.abs(h - h1) <= tol * h1), np.abs(h / h1 - 1).max()
+        assert np.linalg.norm(x - x1) <= 1e-8 * np.linalg.norm(x1)
+    A1.close()
 
 
 def test_eight_ranks_deep_partition():

@@ -817,6 +817,29 @@ def test_double_sweep_box_grid_bitwise(dims):
     A.close()
 
 
+def test_double_sweep_inside_a_captured_graph():
+    """The captured PCG iteration (use_graph) holds the double-sweep launches with their dynamic LDS and the fused transfer launches:
+    replays give the eager solve's bits; switching the kernel off afterwards drops the graph and still gives the same bits."""
+    rp, ci, v = problems.poisson3d(48, 40, 36)
+    n = len(rp) - 1
+    b = np.random.default_rng(83).standard_normal(n)
+    A = sa.sp_matrix_mg(rp, ci, v).set_double_sweep(2).setup(sa.default_params(**QUIET))
+    assert A.level_double_sweep(0)["on"] and A.level_double_sweep(1)["on"]
+    x0 = np.zeros(n)
+    h0, rc0 = A.solve("pcg", b, x0)
+    G = sa.sp_matrix_mg(rp, ci, v).set_double_sweep(2).setup(sa.default_params(**QUIET, use_graph=1))
+    for _ in range(2):
+        x1 = np.zeros(n)
+        h1, rc = G.solve("pcg", b, x1)
+        assert rc == rc0 == 0 and np.array_equal(h0, h1) and np.array_equal(x0, x1)
+    G.set_double_sweep(0)
+    x2 = np.zeros(n)
+    h2, _ = G.solve("pcg", b, x2)
+    assert np.array_equal(h0, h2) and np.array_equal(x0, x2)
+    A.close()
+    G.close()
+
+
 def test_double_sweep_needs_a_box_grid():
     """A 7-point operator that is not the stencil of a full box (one interior coupling removed) keeps the single sweeps;
     so does a 2D grid; the default mode leaves small levels alone."""
@@ -842,3 +865,52 @@ def test_double_sweep_needs_a_box_grid():
     d = D.level_double_sweep(0)
     assert d["grid"] == [30, 30, 30] and not d["on"] and d["double_sweep_us"] == 0.0
     D.close()
+
+
+@pytest.mark.parametrize("dims", [(30, 30, 30), (19, 11, 23), (64, 9, 11), (6, 40, 31), (100, 60, 40), (300, 20, 12)])
+def test_marching_single_stage_kernel(dims):
+    """sdia_box1_kernel (box-grid levels; forced on): the vectors it stores are the table kernel's bit for bit -- the last
+    post-sweep and its prolongating variant against the oracle, residual + pair restriction against the oracle's three steps,
+    A p through the PCG history; its fused dot products against the oracle to 1e-12; whole solves against the table-kernel
+    path: AMG (no fused dot in the cycle) bit for bit, PCG histories to rounding."""
+    nx, ny, nz = dims
+    rp, ci, v = problems.poisson3d(nx, ny, nz)
+    n = len(rp) - 1
+    A = sa.sp_matrix_mg(rp, ci, v).set_marching_ops(2).setup(sa.default_params(**QUIET, max_iter=60))
+    O = oracle.Csr(rp, ci, v)
+    H = oracle.Hierarchy(O)
+    rng = np.random.default_rng(85)
+    on = [l for l in range(A.nlevels - 1) if A.level_marching_ops(l)["on"]]
+    assert 0 in on, [A.level_marching_ops(l) for l in range(A.nlevels)]
+    for l in on:
+        nl = A.level_info(l)["nrow"]
+        x, b = rng.standard_normal(nl), rng.standard_normal(nl)
+        Ol = H.A(l)
+        if A.level_prolong_fused(l):  # last post-sweep + transfer_solution into level l - 1
+            xf = rng.standard_normal(A.level_info(l - 1)["nrow"])
+            want = oracle.transfer_solution(H.P(l - 1), oracle.jacobi(Ol, b, x, 0), xf)
+            assert np.array_equal(A.op_jacobi_prolong(l, b, x, xf), want), (dims, l)
+        if A.level_paired(l) == 1:  # residual + restriction of row pairs + the coarse zero-guess sweep
+            r = oracle.store_residual(Ol, b, x)
+            bc_o = oracle.transfer_residual(H.P(l), r)
+            xc_o = oracle.jacobi(H.A(l + 1), bc_o, np.zeros(len(bc_o)), 0)
+            bc, xc = A.op_residual_restrict(l, b, x)
+            assert np.array_equal(bc, bc_o) and np.array_equal(xc, xc_o), (dims, l)
+    b = rng.standard_normal(n)
+    out = {}
+    for mode in (2, 0):
+        A.set_marching_ops(mode)
+        assert A.level_marching_ops(0)["on"] == (mode == 2)
+        for method in ("amg", "pcg"):
+            x = np.zeros(n)
+            h, rc = A.solve(method, b, x)
+            assert rc in (0, sa.SPARSH_ENOCONV) and len(h) > 0
+            out[(mode, method)] = (np.array(h), x)
+    assert np.array_equal(out[(2, "amg")][0], out[(0, "amg")][0]) and np.array_equal(out[(2, "amg")][1], out[(0, "amg")][1]), dims
+    h2, h0 = out[(2, "pcg")][0], out[(0, "pcg")][0]
+    k = min(len(h2), len(h0), 25)
+    assert abs(len(h2) - len(h0)) <= 1 and np.allclose(h2[:k], h0[:k], rtol=1e-8), dims
+    xo, ho = oracle.solve("pcg", O, b)  # the oracle's history, as far as the capped device run goes
+    m = min(len(h2), len(ho))
+    _hist_ok(h2[:m], ho[:m])
+    A.close()
