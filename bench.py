@@ -744,6 +744,8 @@ def main():
                 # box-grid levels whose smoothing legs run two sweeps per launch, with the setup's timings (us per pair of sweeps)
                 "double_sweep_levels": ({l: A.level_double_sweep(l) for l in range(len(levels)) if A.level_double_sweep(l)["on"]} if world == 1 else None),
                 "single_sweeps_same_process": single_sweeps,
+                # box-grid levels whose epilogue-carrying launches (SpMV + dot, last post-sweep, residual + pair restriction) run the plane-marching kernel
+                "marching_ops_levels": ({l: A.level_marching_ops(l) for l in range(len(levels)) if A.level_marching_ops(l)["on"]} if world == 1 else None),
                 "parallelism": "1 GPU" if world == 1 else (mode_note or (
                     f"{world} GPUs, one process each: contiguous row blocks on the {partitioned_levels} finest levels; deep-halo smoothing "
                     f"(sweeps+1 ghost layers per block, ONE ghost-layer exchange per smoothing leg, grouped ncclSend/ncclRecv of packed "
