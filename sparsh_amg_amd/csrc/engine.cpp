@@ -1582,10 +1582,10 @@ int Engine::apply_A(DevLevel &L, CsrOp op, CsrArgs a)
         if (!deep_exchange(L, 0, xin)) return 0;
         return launch_prefix(L, L.n, op, a);
     }
-    if ((op == OP_SPMV_DOT || op == OP_JACOBI_DOT || op == OP_JACOBI_PROLONG) && (!dist_ || L.replicated) && !a.slice_list &&
+    if ((op == OP_SPMV_DOT || op == OP_JACOBI_DOT || op == OP_JACOBI_PROLONG || op == OP_JACOBI) && (!dist_ || L.replicated) && !a.slice_list &&
         box1_applies(L.A, cfg_)) {
-        // box-grid level: the launches that carry an epilogue run the plane-marching kernel (every x read once)
-        return launch_box1(L.A, op == OP_SPMV_DOT ? 0 : (op == OP_JACOBI_DOT ? 1 : 3), a, L.fine, st_);
+        // box-grid level: the launches that carry an epilogue (and the odd plain sweep of a leg) run the plane-marching kernel: every x read once
+        return launch_box1(L.A, op == OP_SPMV_DOT ? 0 : (op == OP_JACOBI_DOT ? 1 : (op == OP_JACOBI ? 4 : 3)), a, L.fine, st_);
     }
     const CsrFamily fam = csr_family(L.A, cfg_);
     const bool sliced = fam == FAM_SDIA || fam == FAM_SDIA_TAB || fam == FAM_SELL;

@@ -1408,7 +1408,7 @@ __global__ __launch_bounds__(kBoxBlock) void sdia_box2_kernel(BoxArgs g, const d
 // recomputed.  Products in table order, the table kernel's epilogue expressions: the stored vectors are bitwise the table kernel's.  The
 // fused dot products are summed per workgroup of this kernel (one partial each) instead of per 256 rows: same terms, another order of
 // additions -- the one place where the two paths differ, in the last bits of a reduction (reductions are held to 1e-12, section 2).
-enum BoxEpi : int { BOX_SPMV_DOT = 0, BOX_JACOBI_DOT = 1, BOX_RESID_PAIRX = 2, BOX_JACOBI_PROLONG = 3 };
+enum BoxEpi : int { BOX_SPMV_DOT = 0, BOX_JACOBI_DOT = 1, BOX_RESID_PAIRX = 2, BOX_JACOBI_PROLONG = 3, BOX_JACOBI = 4 };
 
 struct Box1Args {
     const double *x, *b;     // input vector, right-hand side (not read by SPMV_DOT)
@@ -1444,7 +1444,7 @@ __global__ __launch_bounds__(kBoxBlock) void sdia_box1_kernel(BoxArgs g, Box1Arg
     const int tid = threadIdx.x;
     const double c0 = g.c[0], c1 = g.c[1], c2 = g.c[2], c3 = g.c[3], c4 = g.c[4], c5 = g.c[5], c6 = g.c[6], om = g.omega;
     constexpr bool kNeedsB = EPI != BOX_SPMV_DOT;
-    constexpr bool kDivides = EPI == BOX_JACOBI_DOT || EPI == BOX_JACOBI_PROLONG;
+    constexpr bool kDivides = EPI == BOX_JACOBI_DOT || EPI == BOX_JACOBI_PROLONG || EPI == BOX_JACOBI;
     DivConst dc3 = {1.0, 1.0, 1.0};
     if constexpr (kDivides) dc3 = make_div_const(c3);
     for (int i = tid; i < cells; i += kBoxBlock) X0[i] = 0.0;
@@ -1509,12 +1509,12 @@ __global__ __launch_bounds__(kBoxBlock) void sdia_box1_kernel(BoxArgs g, Box1Arg
                     a.y[row] = sum;
                     acc += xc[q] * sum;
                 }
-            } else if constexpr (EPI == BOX_JACOBI_DOT) {
+            } else if constexpr (EPI == BOX_JACOBI_DOT || EPI == BOX_JACOBI) {
                 if (v1[q]) {
                     const double h = 1.0 * bk[q] + (-1.0) * sum;
                     const double xnew = xc[q] + div_const(om * h, dc3);
                     a.y[row] = xnew;
-                    acc += xnew * bk[q];
+                    if constexpr (EPI == BOX_JACOBI_DOT) acc += xnew * bk[q];
                 }
             } else if constexpr (EPI == BOX_JACOBI_PROLONG) {
                 if (v1[q]) {
@@ -1976,6 +1976,7 @@ int launch_box1(const DevCsr &A, int epi, const CsrArgs &a, bool finest, hipStre
     case BOX_SPMV_DOT: SPARSH_LAUNCH_BOX1_Q(BOX_SPMV_DOT); break;
     case BOX_JACOBI_DOT: SPARSH_LAUNCH_BOX1_Q(BOX_JACOBI_DOT); break;
     case BOX_RESID_PAIRX: SPARSH_LAUNCH_BOX1_Q(BOX_RESID_PAIRX); break;
+    case BOX_JACOBI: SPARSH_LAUNCH_BOX1_Q(BOX_JACOBI); break;
     default: SPARSH_LAUNCH_BOX1_Q(BOX_JACOBI_PROLONG); break;
     }
 #undef SPARSH_LAUNCH_BOX1_Q

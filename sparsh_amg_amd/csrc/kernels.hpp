@@ -202,7 +202,8 @@ void launch_box_resid_pair(const DevCsr &A, int axis, const double *x, const dou
                            double *bc, double *xc, hipStream_t st);
 // Single-stage plane-marching kernel on a box-grid level (sdia_box1_kernel); epi: 0 y = A x + partial x.Ax, 1 Jacobi sweep into y + partial
 // y.b, 2 residual + pair restriction (aggregates = row pairs; y = coarse rhs, y2 = coarse zero-guess sweep, d / dconst = coarse diagonal),
-// 3 Jacobi sweep added to the finer iterate y2 (members / nfine as OP_JACOBI_PROLONG).  Returns the number of partial sums written.
+// 3 Jacobi sweep added to the finer iterate y2 (members / nfine as OP_JACOBI_PROLONG), 4 plain Jacobi sweep into y (the odd sweep of a leg
+// that runs double sweeps).  Returns the number of partial sums written.
 bool box1_plan(DevCsr &A);
 bool box1_applies(const DevCsr &A, const KernelConfig &cfg);
 int launch_box1(const DevCsr &A, int epi, const CsrArgs &a, bool finest, hipStream_t st);

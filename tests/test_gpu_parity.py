@@ -785,7 +785,7 @@ def test_double_sweep_box_grid_bitwise(dims):
     nx, ny, nz = dims
     rp, ci, v = problems.poisson3d(nx, ny, nz)
     n = len(rp) - 1
-    A = sa.sp_matrix_mg(rp, ci, v).set_double_sweep(2).setup(sa.default_params(**QUIET, max_iter=60))
+    A = sa.sp_matrix_mg(rp, ci, v).set_double_sweep(2).set_marching_ops(2).setup(sa.default_params(**QUIET, max_iter=60))  # (odd sweeps: the marching kernel)
     O = oracle.Csr(rp, ci, v)
     H = oracle.Hierarchy(O)
     info = [A.level_double_sweep(l) for l in range(A.nlevels)]
@@ -886,6 +886,8 @@ def test_marching_single_stage_kernel(dims):
         nl = A.level_info(l)["nrow"]
         x, b = rng.standard_normal(nl), rng.standard_normal(nl)
         Ol = H.A(l)
+        for sweeps in (1, 3):  # plain sweeps through the same kernel
+            assert np.array_equal(A.op_jacobi(l, b, x, sweeps), oracle.jacobi(Ol, b, x, sweeps - 1)), (dims, l, sweeps)
         if A.level_prolong_fused(l):  # last post-sweep + transfer_solution into level l - 1
             xf = rng.standard_normal(A.level_info(l - 1)["nrow"])
             want = oracle.transfer_solution(H.P(l - 1), oracle.jacobi(Ol, b, x, 0), xf)
