@@ -1,7 +1,7 @@
 """Same-process A/B of the fused residual + restriction launch (sparsh_set_paired_restriction) or of the fused last post-sweep
 + prolongation (sparsh_set_fused_prolongation) inside the PCG iteration.
 
-    python tools/pair_restrict_ab.py [--what pair|prolong|diag|box2] [--n 216] [--dim 3] [--iters 96] [--reps 3] [--out FILE]
+    python tools/fusion_ab.py [--what pair|prolong|diag|box2] [--n 216] [--dim 3] [--iters 96] [--reps 3] [--out FILE]
 
 One handle, one hierarchy; the setting is toggled between timed runs of `iters` PCG iterations (restart every 48, as bench.py
 does), alternating on / off so that drift of the box hits both sides alike.  Prints it/s per run and the median of each side.
