@@ -296,22 +296,27 @@ def main():
         level 0 the Krylov step: SpMV with the p.Ap dot, cg_update (p, Ap, x, r, d read; x, r, z written), p update."""
         total = 0
         prev_paired = False
+        zero_written = {}
         dvec = [0 if H.level_constant_diagonal(l)[0] else 8 for l in range(len(levels))]  # bytes per row of a level's diag[] stream where it is read
         for l, (nl, nnzl, pn, pnnz) in enumerate(levels[:-1]):
             ncl = levels[l + 1][0]
+            from_b = world == 1 and H.level_double_sweep(l)["on"] and sweeps >= 3  # the down-leg's first launch: sweeps 1 - 3 from b alone (16 B per row)
             if world == 1 and H.level_double_sweep(l)["on"]:
                 # both legs: (sweeps - 1) plain sweeps run as pairs (one pass over x, b, y: 24 B per row), the rest -- and the last
                 # post-sweep, which carries the dot / the prolongation -- as single sweeps
                 pairs = 2 * ((sweeps - 1) // 2)
                 singles = 2 * ((sweeps - 1) % 2) + 1
-                total += pairs * 24 * nl + singles * layout_bytes(H, nl, nnzl, l, 3)
+                total += pairs * 24 * nl + singles * layout_bytes(H, nl, nnzl, l, 3) - (8 * nl if from_b else 0)
             else:
                 total += (2 * sweeps - 1) * layout_bytes(H, nl, nnzl, l, 3)
-            if l > 0 and not prev_paired:
+            zero_written[l] = not from_b
+            if l > 0 and not prev_paired and not from_b:
                 total += (16 + dvec[l]) * nl
             prev_paired = H.level_paired(l)
             if prev_paired:  # residual + restriction + the coarse zero-guess sweep in one launch: x, b in; b_c, x_c out, d_c in
-                total += layout_bytes(H, nl, nnzl, l, 2) + (16 + dvec[l + 1]) * ncl
+                nxt = levels[l + 1]
+                nxt_from_b = world == 1 and l + 1 < len(levels) - 1 and H.level_double_sweep(l + 1)["on"] and sweeps >= 3
+                total += layout_bytes(H, nl, nnzl, l, 2) + (8 if nxt_from_b else 16 + dvec[l + 1]) * ncl
             else:
                 total += layout_bytes(H, nl, nnzl, l, 3) + (4 * (ncl + 1) + 4 * pnnz + 8 * nl + 8 * ncl)
             form = H.level_prolong_fused(l + 1)
@@ -322,7 +327,7 @@ def main():
                 total += 4 * nl + 8 * ncl + 16 * nl
         total += coarse["bytes"] + 16 * levels[-1][0]
         n0, nnz0 = levels[0][0], levels[0][1]
-        total += layout_bytes(H, n0, nnz0, 0, 2) + (56 + dvec[0]) * n0 + 24 * n0
+        total += layout_bytes(H, n0, nnz0, 0, 2) + ((48 if zero_written.get(0) is False else 56 + dvec[0])) * n0 + 24 * n0
         return total
 
     def double_sweep(H):

@@ -209,6 +209,12 @@ int sparsh_set_double_sweep(sparsh_handle h, int mode);
  * {points per thread, lines per tile, planes per chunk}, the setup's timing of the last post-sweep + dot through the table kernel
  * and through this one (us, 0: not timed). */
 int sparsh_set_marching_ops(sparsh_handle h, int mode);
+/* Double-sweep levels: a smoothing leg that starts from a zero guess (every down-leg below the finest level, and the finest level's
+ * inside PCG) runs its first THREE sweeps as one launch: the matrix-free first sweep x = omega b / d (parallel::jacobi_smoother from
+ * x = 0) is evaluated where the double sweep would load its input, from the right-hand side the two stencil stages read anyway, so
+ * the iterate is not read at all (16 instead of 31 bytes per row for that launch).  Bitwise the three separate sweeps.
+ * enable: 1 (default) / 0 (A/B). */
+int sparsh_set_zero_start(sparsh_handle h, int enable);
 int sparsh_level_marching_ops(sparsh_handle h, int level, int *on, int *plan, double *table_us, double *marching_us);
 int sparsh_level_double_sweep(sparsh_handle h, int level, int *on, int *dims, int *plan, double *single_us, double *double_us);
 int sparsh_level_constant_diagonal(sparsh_handle h, int level, int *is_const, double *value);

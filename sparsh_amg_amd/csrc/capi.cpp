@@ -440,6 +440,14 @@ int sparsh_level_double_sweep(sparsh_handle h, int level, int *on, int *dims, in
     return SPARSH_OK;
 }
 
+int sparsh_set_zero_start(sparsh_handle h, int enable)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    h->eng->kernel_cfg().zero_start = enable != 0;
+    h->eng->config_changed();
+    return SPARSH_OK;
+}
+
 int sparsh_set_marching_ops(sparsh_handle h, int mode)
 {
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");

@@ -1784,7 +1784,12 @@ void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, doubl
     }
     int k = 0;
     bool dot_done = false;
-    if (x_zero && sweeps > 0) {
+    const bool special_last = dot_partial || prolong_to;  // the last sweep carries an epilogue of its own
+    if (x_zero && sweeps > 0 && zero_start(L) && sweeps - (special_last ? 1 : 0) >= 3) {
+        // zero guess on a double-sweep level: sweeps 1 - 3 in one launch that reads b alone (whatever zero-guess sweep a producer left in x is not used)
+        launch_box2(L.A, nullptr, b, L.x, prm_.omega, L.fine, st_, true);
+        k = 3;
+    } else if (x_zero && sweeps > 0) {
         if (!zero_done) launch_jacobi_zero(L.n, b, diag_stream(L), L.diag_const, prm_.omega, L.x, st_);
         k = 1;
     }
@@ -1793,7 +1798,6 @@ void Engine::smooth(DevLevel &L, const double *b, int sweeps, bool x_zero, doubl
     int in_run = 0;
     const bool pairs = (!dist_ || L.replicated) && box2_applies(L.A, cfg_);
     bool timed_open = timed;
-    const bool special_last = dot_partial || prolong_to;  // the last sweep carries an epilogue of its own
     for (; k < sweeps; ++k) {
         const bool last = (k == sweeps - 1);
         if (pairs && k + 2 <= sweeps - (special_last ? 1 : 0)) {  // two plain sweeps in one pass over the vectors
@@ -1889,14 +1893,16 @@ void Engine::vcycle(const double *b0, bool x0_zero, double *dot_partial, int *do
             continue;
         }
         smooth(L, L.b, nu, l > 0 || x0_zero, nullptr, nullptr, zero_done);  // coarse levels start from x = 0 (fill, :204)
+        // (a level that starts its leg with the three-sweep launch reads b alone: nobody needs its zero-guess sweep written)
+        const bool next_from_b = l + 1 < last && nu >= 3 && zero_start(lev_[l + 1]);
         if (level_paired(l)) {
             // store_residual + transfer_residual (+ x_{l+1} = omega*b/d) in one launch: r_l never goes to memory
-            op_residual_restrict(l, L.b, L.x, lev_[l + 1].b, lev_[l + 1].x);
+            op_residual_restrict(l, L.b, L.x, lev_[l + 1].b, next_from_b ? nullptr : lev_[l + 1].x);
             zero_done = true;
             continue;
         }
         op_residual(l, L.b, L.x, L.r);                                      // store_residual
-        zero_done = op_restrict(l, L.r, lev_[l + 1].b, nu > 0);             // transfer_residual (+ x_{l+1} = omega*b/d)
+        zero_done = op_restrict(l, L.r, lev_[l + 1].b, nu > 0 && !next_from_b);  // transfer_residual (+ x_{l+1} = omega*b/d)
     }
     op_coarse(lev_[last].b, lev_[last].x);  // Direct_Solver_Pardiso_solve
     for (int l = last; l > 0; --l) {
@@ -2007,7 +2013,9 @@ void Engine::pcg_body(bool precond, int slot)
     // x += alpha p ; r -= alpha Ap ; r.r -- with a preconditioner the r.r partials wait in part1_ and
     // are reduced together with z.r after the V-cycle: one finalize launch (one all-reduce) less
     // with the fp64 V-cycle behind it the update also writes the cycle's zero-guess sweep of level 0 (z0 = omega r / d)
-    const bool fuse_zero = cfg_.fuse_cg_zero && precond && !f32_ready_ && lev_.size() > 1 && !lev_[0].deep && prm_.sweeps > 0;
+    // (... unless the cycle's first launch on level 0 is the three-sweep one, which reads r alone)
+    const bool fuse_zero = cfg_.fuse_cg_zero && precond && !f32_ready_ && lev_.size() > 1 && !lev_[0].deep && prm_.sweeps > 0 &&
+                           !(prm_.sweeps >= 3 && zero_start(lev_[0]));
     if (fuse_zero)
         launch_cg_update_zero(n, scal_, p, Ap, x, r, part1_, &nb, diag_stream(lev_[0]), lev_[0].diag_const, prm_.omega, lev_[0].x, st_, cfg_.cg_nt);
     else

@@ -112,6 +112,8 @@ public:
     void config_changed() { drop_graph(); }
     // diag[] of a level for the kernels that only divide by it: nullptr (+ diag_const) where it is one constant
     const double *diag_stream(const DevLevel &L) const { return cfg_.const_diag && L.diag_is_const ? nullptr : L.diag; }
+    // a smoothing leg of this level that starts from a zero guess runs sweeps 1 - 3 as one launch reading b alone
+    bool zero_start(const DevLevel &L) const { return cfg_.zero_start && (!dist_ || L.replicated) && !L.deep && box2_applies(L.A, cfg_); }
     // whether level l's last post-sweep also prolongates into level l - 1 (OP_JACOBI_PROLONG)
     bool level_prolong_fused(int l) const
     {

@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(kBlock) void sdia_tab_kernel(int nrow, int xlen, in
         double dv = 0.0;
         double dpair = 1.0;  // RESID_PAIR: diagonal of the coarse row this even lane writes (in flight beside the gathers)
         if constexpr (OP == OP_RESID_PAIR) {
-            if (!a.d) dpair = a.dconst;
+            if (!a.d || !a.y2) dpair = a.dconst;
             else if (has_row && !(lane & 1)) dpair = a.d[row >> 1];
         }
         // lexicographic grid stencils: -1, 0, +1 in adjacent slots (launch-uniform test on kernel arguments)
@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(kBlock) void sdia_tab_kernel(int nrow, int xlen, in
                 double bc = 0.0 + ri;
                 if (row + 1 < nrow) bc = bc + rn;
                 a.y[row >> 1] = bc;
-                a.y2[row >> 1] = a.omega * bc / dpair;
+                if (a.y2) a.y2[row >> 1] = a.omega * bc / dpair;
             }
         } else {
             if (has_row) acc = row_epilogue<OP>(a, row, sum, o);
@@ -1278,7 +1278,9 @@ struct BoxArgs {
     double omega;
 };
 
-template <int Q, int TAG>
+// ZERO: the leg starts from a zero guess -- x0 is not read: the first (matrix-free) sweep x1 = omega b / d is evaluated where x0 would be
+// loaded, from the right-hand side the stages need anyway, so the launch performs the first THREE sweeps of the leg (y = J(J(omega b / d)))
+template <int Q, int TAG, bool ZERO>
 __global__ __launch_bounds__(kBoxBlock) void sdia_box2_kernel(BoxArgs g, const double *__restrict__ x, const double *__restrict__ b,
                                                                double *__restrict__ y)
 {
@@ -1308,6 +1310,7 @@ __global__ __launch_bounds__(kBoxBlock) void sdia_box2_kernel(BoxArgs g, const d
     bool v0[Q], v1[Q], v2[Q];
     int sidx[Q];
     double xm[Q], xc[Q], xp[Q], bk[Q], bp[Q], x1m[Q], x1c[Q];
+    double bq[Q];  // ZERO: b of plane k + 1 (it arrived as the source of xp)
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const int p = tid + kBoxBlock * q;
@@ -1317,18 +1320,32 @@ __global__ __launch_bounds__(kBoxBlock) void sdia_box2_kernel(BoxArgs g, const d
         v0[q] = p < R0 && jr >= 0 && jr < ny;
         v1[q] = v0[q] && lr >= 1 && lr <= TY + 2;
         v2[q] = v0[q] && lr >= 2 && lr <= TY + 1;
-        xm[q] = xc[q] = xp[q] = bk[q] = bp[q] = x1m[q] = x1c[q] = 0.0;
+        xm[q] = xc[q] = xp[q] = bk[q] = bp[q] = x1m[q] = x1c[q] = bq[q] = 0.0;
     }
     const int ks = z0 - 1;  // first plane of the first sweep (-1: does not exist)
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const int p = tid + kBoxBlock * q;
-        if (v0[q]) {
-            if (ks >= 1) xm[q] = x[(long)(ks - 1) * P + base + p];
-            if (ks >= 0) xc[q] = x[(long)ks * P + base + p];
-            if (ks + 1 < nz) xp[q] = x[(long)(ks + 1) * P + base + p];
+        if constexpr (ZERO) {
+            if (v0[q]) {
+                if (ks >= 1) xm[q] = div_const(om * b[(long)(ks - 1) * P + base + p], dc);
+                if (ks >= 0) {
+                    bk[q] = b[(long)ks * P + base + p];
+                    xc[q] = div_const(om * bk[q], dc);
+                }
+                if (ks + 1 < nz) {
+                    bq[q] = b[(long)(ks + 1) * P + base + p];
+                    xp[q] = div_const(om * bq[q], dc);
+                }
+            }
+        } else {
+            if (v0[q]) {
+                if (ks >= 1) xm[q] = x[(long)(ks - 1) * P + base + p];
+                if (ks >= 0) xc[q] = x[(long)ks * P + base + p];
+                if (ks + 1 < nz) xp[q] = x[(long)(ks + 1) * P + base + p];
+            }
+            if (v1[q] && ks >= 0) bk[q] = b[(long)ks * P + base + p];
         }
-        if (v1[q] && ks >= 0) bk[q] = b[(long)ks * P + base + p];
     }
     __syncthreads();
     for (int k = ks; k <= z1; ++k) {  // every thread of the workgroup runs the same z1 - ks + 1 steps
@@ -1340,8 +1357,12 @@ __global__ __launch_bounds__(kBoxBlock) void sdia_box2_kernel(BoxArgs g, const d
             xn[q] = 0.0;
             bn[q] = 0.0;
             if (k + 1 <= z1) {
-                if (v0[q] && k + 2 < nz) xn[q] = x[(long)(k + 2) * P + base + p];
-                if (v1[q] && k + 1 < nz) bn[q] = b[(long)(k + 1) * P + base + p];
+                if constexpr (ZERO) {
+                    if (v0[q] && k + 2 < nz) xn[q] = b[(long)(k + 2) * P + base + p];  // raw b of plane k + 2 (x of that plane follows from it below)
+                } else {
+                    if (v0[q] && k + 2 < nz) xn[q] = x[(long)(k + 2) * P + base + p];
+                    if (v1[q] && k + 1 < nz) bn[q] = b[(long)(k + 1) * P + base + p];
+                }
             }
         }
 #pragma unroll
@@ -1394,9 +1415,16 @@ __global__ __launch_bounds__(kBoxBlock) void sdia_box2_kernel(BoxArgs g, const d
             x1c[q] = x1k[q];
             xm[q] = xc[q];
             xc[q] = xp[q];
-            xp[q] = xn[q];
             bp[q] = bk[q];
-            bk[q] = bn[q];
+            if constexpr (ZERO) {
+                bk[q] = bq[q];
+                bq[q] = xn[q];
+                xp[q] = 0.0;
+                if (v0[q] && k + 1 <= z1 && k + 2 < nz) xp[q] = div_const(om * xn[q], dc);
+            } else {
+                xp[q] = xn[q];
+                bk[q] = bn[q];
+            }
         }
     }
 }
@@ -1545,7 +1573,7 @@ __global__ __launch_bounds__(kBoxBlock) void sdia_box1_kernel(BoxArgs g, Box1Arg
                     double bc = 0.0 + ri;
                     bc = bc + rn;
                     a.y[J] = bc;
-                    a.y2[J] = om * bc / (a.dc ? a.dc[J] : a.dconst);
+                    if (a.y2) a.y2[J] = om * bc / (a.dc ? a.dc[J] : a.dconst);  // (nullptr: the coarse leg starts from b itself)
                 }
             }
         }
@@ -1615,13 +1643,13 @@ __global__ __launch_bounds__(kBlock) void box_resid_pair_kernel(BoxArgs g, int n
     const int f1 = i + nx * (j + ny * k);
     const int f2 = f1 + (AXIS == 1 ? nx : nx * ny);
     const int Jout = rev ? nc - 1 - J : J;  // (the matching of some levels numbers its aggregates from the far end of the box)
-    const double dj = dc ? dc[Jout] : dconst;
+    const double dj = !xc ? 1.0 : (dc ? dc[Jout] : dconst);
     const double r1 = box_residual(g, x, b, f1, i, j, k);
     const double r2 = box_residual(g, x, b, f2, i, j + (AXIS == 1 ? 1 : 0), k + (AXIS == 2 ? 1 : 0));
     double s = 0.0 + r1;
     s = s + r2;
     bc[Jout] = s;
-    xc[Jout] = g.omega * s / dj;
+    if (xc) xc[Jout] = g.omega * s / dj;  // (nullptr: the coarse leg starts from b itself)
 }
 
 // ------------------------------------------------------------------ fp32 preconditioner kernels
@@ -1989,7 +2017,7 @@ bool box2_applies(const DevCsr &A, const KernelConfig &c)
     return c.box2 != 0 && A.box_on && A.box_q > 0 && csr_family(A, c) == FAM_SDIA_TAB;
 }
 
-void launch_box2(const DevCsr &A, const double *x, const double *b, double *y, double omega, bool finest, hipStream_t st)
+void launch_box2(const DevCsr &A, const double *x, const double *b, double *y, double omega, bool finest, hipStream_t st, bool from_zero)
 {
     BoxArgs g;
     g.nx = A.box_nx;
@@ -2003,10 +2031,15 @@ void launch_box2(const DevCsr &A, const double *x, const double *b, double *y, d
     const int chunks = (g.nz + g.CZ - 1) / g.CZ;
     const dim3 grid(g.ytiles * chunks), block(kBoxBlock);
     const size_t lds = box2_lds_bytes(g.nx, g.TY);
-#define SPARSH_LAUNCH_BOX(Q_)                                                                        \
-    do {                                                                                             \
-        if (finest) hipLaunchKernelGGL((sdia_box2_kernel<Q_, 1>), grid, block, lds, st, g, x, b, y); \
-        else hipLaunchKernelGGL((sdia_box2_kernel<Q_, 0>), grid, block, lds, st, g, x, b, y);        \
+#define SPARSH_LAUNCH_BOX(Q_)                                                                                       \
+    do {                                                                                                            \
+        if (from_zero) {                                                                                            \
+            if (finest) hipLaunchKernelGGL((sdia_box2_kernel<Q_, 1, true>), grid, block, lds, st, g, x, b, y);      \
+            else hipLaunchKernelGGL((sdia_box2_kernel<Q_, 0, true>), grid, block, lds, st, g, x, b, y);             \
+        } else {                                                                                                    \
+            if (finest) hipLaunchKernelGGL((sdia_box2_kernel<Q_, 1, false>), grid, block, lds, st, g, x, b, y);     \
+            else hipLaunchKernelGGL((sdia_box2_kernel<Q_, 0, false>), grid, block, lds, st, g, x, b, y);            \
+        }                                                                                                           \
     } while (0)
     if (A.box_q == 4) SPARSH_LAUNCH_BOX(4);
     else if (A.box_q == 3) SPARSH_LAUNCH_BOX(3);

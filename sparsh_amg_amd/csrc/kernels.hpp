@@ -110,6 +110,8 @@ struct KernelConfig {
     bool fuse_cg_zero = true; // PCG: the cg_update kernel also writes the V-cycle's zero-guess sweep of level 0
     int alt_dir = 1;          // consecutive sweeps of a smoothing leg walk the level in alternating directions (CsrArgs::reverse):
                               // 0 never, 1 where a sweep streams more than 640 MB (2.5x the Infinity Cache), 2 always
+    bool zero_start = true;    // double-sweep levels: a leg that starts from a zero guess runs its first three sweeps as one launch that
+                               // reads only the right-hand side (launch_box2 from_zero)
     int box1 = 1;              // box-grid levels: the launches with an epilogue of their own (SpMV + dot, last post-sweep + dot / + prolongation,
                                // residual + pair restriction) through the plane-marching kernel (sdia_box1_kernel): 0 never, 1 where the setup
                                // measured it faster than the table kernel (levels of >= 400 000 rows), 2 wherever a plan exists
@@ -194,7 +196,8 @@ CsrFamily csr_family(const DevCsr &A, const KernelConfig &cfg);
 // box2_plan fills box_q/ty/cz (false: no plan -- lines too long for the LDS region); box2_applies = the level runs it under cfg
 bool box2_plan(DevCsr &A);
 bool box2_applies(const DevCsr &A, const KernelConfig &cfg);
-void launch_box2(const DevCsr &A, const double *x, const double *b, double *y, double omega, bool finest, hipStream_t st);
+// from_zero: the leg starts from x = 0: x is not read, y = J(J(omega b / d)) = the first three sweeps of the leg
+void launch_box2(const DevCsr &A, const double *x, const double *b, double *y, double omega, bool finest, hipStream_t st, bool from_zero = false);
 // box-grid level whose aggregates pair a point with its neighbour one line (axis +-1) or one plane (axis +-2) up: residual, restriction and
 // the coarse zero-guess sweep in one launch (dc == nullptr: constant coarse diagonal dconst); axis < 0: aggregates numbered from the far
 // end of the coarse box (J = nc - 1 - lexicographic index)

@@ -800,7 +800,17 @@ def test_double_sweep_box_grid_bitwise(dims):
         Ol = H.A(l)
         for sweeps in (2, 3, 4, 7):
             assert np.array_equal(A.op_jacobi(l, b, x, sweeps), oracle.jacobi(Ol, b, x, sweeps - 1)), (dims, l, sweeps)
-        assert np.array_equal(A.op_jacobi(l, b, np.zeros(nl), 7, x_is_zero=True), oracle.jacobi(Ol, b, np.zeros(nl), 6)), (dims, l)
+        for sweeps in (2, 3, 4, 5, 7):  # from a zero guess: sweeps 1 - 3 are one launch reading b alone (sparsh_set_zero_start)
+            assert np.array_equal(A.op_jacobi(l, b, np.zeros(nl), sweeps, x_is_zero=True), oracle.jacobi(Ol, b, np.zeros(nl), sweeps - 1)), (dims, l, sweeps)
+        bz = b.copy()
+        bz[:: 7] = 0.0  # zeros in the right-hand side take the plain-division branch of div_const
+        assert np.array_equal(A.op_jacobi(l, bz, np.zeros(nl), 3, x_is_zero=True), oracle.jacobi(Ol, bz, np.zeros(nl), 2)), (dims, l)
+    A.set_zero_start(False)
+    l0 = boxes[0]
+    nl = A.level_info(l0)["nrow"]
+    x, b = rng.standard_normal(nl), rng.standard_normal(nl)
+    assert np.array_equal(A.op_jacobi(l0, b, np.zeros(nl), 7, x_is_zero=True), oracle.jacobi(H.A(l0), b, np.zeros(nl), 6))
+    A.set_zero_start(True)
     b = rng.standard_normal(n)
     out = {}
     for mode in (2, 0):

@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--iters", type=int, default=96)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--out", default=None)
-    ap.add_argument("--what", default="pair", choices=["pair", "prolong", "diag", "box2", "box1"])
+    ap.add_argument("--what", default="pair", choices=["pair", "prolong", "diag", "box2", "box1", "zero"])
     args = ap.parse_args()
     rp, ci, v = problems.poisson3d(args.n) if args.dim == 3 else problems.poisson2d(args.n)
     n = len(rp) - 1
@@ -38,6 +38,9 @@ def main():
     elif args.what == "box2":
         paired = [(l, A.level_double_sweep(l)) for l in range(A.nlevels) if A.level_double_sweep(l)["grid"][0] > 0]
         toggle = lambda on: A.set_double_sweep(1 if on else 0)  # noqa: E731
+    elif args.what == "zero":
+        paired = [l for l in range(A.nlevels) if A.level_double_sweep(l)["on"]]
+        toggle = A.set_zero_start
     elif args.what == "box1":
         paired = [(l, A.level_marching_ops(l)) for l in range(A.nlevels) if A.level_marching_ops(l)["points_per_thread"] > 0]
         toggle = lambda on: A.set_marching_ops(1 if on else 0)  # noqa: E731
