@@ -314,7 +314,6 @@ def main():
                 total += (16 + dvec[l]) * nl
             prev_paired = H.level_paired(l)
             if prev_paired:  # residual + restriction + the coarse zero-guess sweep in one launch: x, b in; b_c, x_c out, d_c in
-                nxt = levels[l + 1]
                 nxt_from_b = world == 1 and l + 1 < len(levels) - 1 and H.level_double_sweep(l + 1)["on"] and sweeps >= 3
                 total += layout_bytes(H, nl, nnzl, l, 2) + (8 if nxt_from_b else 16 + dvec[l + 1]) * ncl
             else:

@@ -92,7 +92,7 @@ def collect(d, jacobi_kernel=None):
             key = "dot"
         elif "copy_int_kernel" in name:
             key = "copy_int"
-        elif jacobi_kernel == "sdia_box2_kernel" and "sdia_box2_kernel<" in name and ", 1>" in name:
+        elif jacobi_kernel == "sdia_box2_kernel" and "sdia_box2_kernel<" in name and ", 1, false>" in name:  # finest level, not the from-zero variant
             key = "jacobi"
             out["_kind"] = [4.0]
         elif ("sdia_kernel<2" in name or "sdia_tab_kernel<2" in name or "sdia_ord_kernel<2" in name or "sell_kernel<2" in name
