@@ -926,3 +926,68 @@ def test_marching_single_stage_kernel(dims):
     m = min(len(h2), len(ho))
     _hist_ok(h2[:m], ho[:m])
     A.close()
+
+
+def _stencil7(nx, ny, nz, c):
+    """7-point operator on an nx x ny x nz box with a distinct constant per offset: c = (down, south, west, centre, east, north, up)."""
+    import scipy.sparse as sp
+
+    def shift(n, k):
+        return sp.diags([np.ones(n - 1)], [k], shape=(n, n))
+
+    Ix, Iy, Iz = sp.identity(nx), sp.identity(ny), sp.identity(nz)
+    A = (c[3] * sp.kron(Iz, sp.kron(Iy, Ix)) + c[2] * sp.kron(Iz, sp.kron(Iy, shift(nx, -1))) + c[4] * sp.kron(Iz, sp.kron(Iy, shift(nx, 1)))
+         + c[1] * sp.kron(Iz, sp.kron(shift(ny, -1), Ix)) + c[5] * sp.kron(Iz, sp.kron(shift(ny, 1), Ix))
+         + c[0] * sp.kron(shift(nz, -1), sp.kron(Iy, Ix)) + c[6] * sp.kron(shift(nz, 1), sp.kron(Iy, Ix))).tocsr()
+    A.sort_indices()
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+
+
+@pytest.mark.parametrize("dims,coef", [
+    ((40, 36, 32), (-2.5, -2.0, -1.5, 10.0, -0.5, -1.0, -0.7)),   # seven different constants: every slot of the stencil is told apart
+    ((36, 40, 30), (-0.3, -3.0, -0.6, 9.0, -0.9, -2.1, -0.4)),    # strongest coupling along y
+    ((30, 28, 44), (-3.1, -0.2, -0.8, 9.5, -0.6, -0.4, -2.9)),    # ... along z
+])
+def test_box_kernels_with_a_different_constant_per_offset(dims, coef):
+    """The box-grid kernels (double sweep incl. its from-zero variant, plane-marching single stage, residual + restriction along x, y, z)
+    on a non-symmetric constant-coefficient stencil: a mix-up of two offsets cannot hide behind equal coefficients.  Operator level,
+    against the oracle, bit for bit, on every level that qualifies."""
+    nx, ny, nz = dims
+    rp, ci, v = _stencil7(nx, ny, nz, coef)
+    A = sa.sp_matrix_mg(rp, ci, v).set_double_sweep(2).set_marching_ops(2).setup(sa.default_params(**QUIET))
+    O = oracle.Csr(rp, ci, v)
+    H = oracle.Hierarchy(O)
+    assert A.nlevels == H.nlevels >= 3
+    rng = np.random.default_rng(87)
+    boxes = [l for l in range(A.nlevels - 1) if A.level_double_sweep(l)["on"]]
+    assert 0 in boxes and A.level_double_sweep(0)["grid"] == [nx, ny, nz]
+    kinds = set()
+    for l in boxes:
+        nl = A.level_info(l)["nrow"]
+        x, b = rng.standard_normal(nl), rng.standard_normal(nl)
+        Ol = H.A(l)
+        for sweeps in (1, 2, 3, 7):
+            assert np.array_equal(A.op_jacobi(l, b, x, sweeps), oracle.jacobi(Ol, b, x, sweeps - 1)), (dims, l, sweeps)
+        for sweeps in (3, 4, 7):
+            assert np.array_equal(A.op_jacobi(l, b, np.zeros(nl), sweeps, x_is_zero=True), oracle.jacobi(Ol, b, np.zeros(nl), sweeps - 1)), (dims, l, sweeps)
+        assert np.array_equal(A.op_spmv(l, x), oracle.spmv(Ol, x)) and np.array_equal(A.op_residual(l, b, x), oracle.store_residual(Ol, b, x))
+        if A.level_paired(l):
+            kinds.add(A.level_paired(l))
+            r = oracle.store_residual(Ol, b, x)
+            bc_o = oracle.transfer_residual(H.P(l), r)
+            xc_o = oracle.jacobi(H.A(l + 1), bc_o, np.zeros(len(bc_o)), 0)
+            bc, xc = A.op_residual_restrict(l, b, x)
+            assert np.array_equal(bc, bc_o) and np.array_equal(xc, xc_o), (dims, l, A.level_paired(l))
+        if A.level_prolong_fused(l):
+            xf = rng.standard_normal(A.level_info(l - 1)["nrow"])
+            want = oracle.transfer_solution(H.P(l - 1), oracle.jacobi(Ol, b, x, 0), xf)
+            assert np.array_equal(A.op_jacobi_prolong(l, b, x, xf), want), (dims, l)
+    assert kinds, "no level took a fused residual + restriction"
+    # one V-cycle and a few PCG / BiCGStab iterations against the oracle (the operator is not symmetric: only the first steps are compared)
+    n = len(rp) - 1
+    b = rng.standard_normal(n)
+    xa = np.zeros(n)
+    ha, _ = A.vcycle(b, xa, iterations=3)
+    xo, ho = H.solve(b, iterations=3)
+    assert np.allclose(ha, ho, rtol=1e-10) and np.linalg.norm(xa - xo) <= 1e-10 * np.linalg.norm(xo)
+    A.close()
