@@ -1903,7 +1903,9 @@ size_t box2_lds_bytes(int nx, int TY) { return (size_t)2 * ((size_t)(TY + 4) * (
 
 // Plan of the double sweep: Q points per thread, TY lines per tile, CZ planes per chunk.  Cost model (checked against
 // tools/micro/box2_proto on MI355X: 216^3 Q4/TY14/CZ14 57 us, Q3/TY10/CZ14 94 us, 108x216x216 Q4/TY33/CZ6 34 us, Q2/TY14/CZ14 38 us):
-// a workgroup's time ~ (CZ + 2) steps x Q points, the launch takes ceil(workgroups / 256 CUs) rounds of it.
+// a workgroup's time ~ (CZ + 2) steps x Q points, the launch takes ceil(workgroups / 256 CUs) rounds of it.  The Q = 2 instance needs
+// 62 VGPRs and 31 KB of LDS, so two of its workgroups share a CU: 512 slots, each running at ~1/1.6 of the speed it has alone
+// (108 x 216 x 216: Q2/TY14/CZ7 = 496 workgroups 32.9 us against 35.8 for CZ14 = 256 and 35.4 for Q3/TY24/CZ8 = 243).
 bool box2_plan(DevCsr &A)
 {
     A.box_q = A.box_ty = A.box_cz = 0;
@@ -1918,8 +1920,10 @@ bool box2_plan(DevCsr &A)
         for (int zch = 1; zch <= nz; ++zch) {
             const int CZ = (nz + zch - 1) / zch;
             const int chunks = (nz + CZ - 1) / CZ;
-            const long wgs = (long)ytiles * chunks, rounds = (wgs + 255) / 256;
-            const long cost = rounds * (CZ + 2) * Q;
+            const long wgs = (long)ytiles * chunks;
+            long cost;  // in tenths of a step of one point
+            if (Q == 2 && wgs > 256) cost = ((wgs + 511) / 512) * (CZ + 2) * Q * 16;
+            else cost = ((wgs + 255) / 256) * (CZ + 2) * Q * 10;
             if (best < 0 || cost < best) {
                 best = cost;
                 A.box_q = Q;
