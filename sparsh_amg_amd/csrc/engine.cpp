@@ -707,6 +707,23 @@ void Engine::tune_box2()
             };
             L.box1_table_us = timed1(false);
             L.box1_us = timed1(true);
+            {  // the plan that lets two workgroups share a CU, if it is another one: keep the faster
+                const int q0 = L.A.box1_q, ty0 = L.A.box1_ty, cz0 = L.A.box1_cz;
+                if (box1_plan(L.A, true) && (L.A.box1_q != q0 || L.A.box1_ty != ty0 || L.A.box1_cz != cz0)) {
+                    const double t_alt = timed1(true);
+                    if (t_alt < L.box1_us) {
+                        L.box1_us = t_alt;
+                    } else {
+                        L.A.box1_q = q0;
+                        L.A.box1_ty = ty0;
+                        L.A.box1_cz = cz0;
+                    }
+                } else {
+                    L.A.box1_q = q0;
+                    L.A.box1_ty = ty0;
+                    L.A.box1_cz = cz0;
+                }
+            }
             L.A.box1_on = L.box1_us < 0.97 * L.box1_table_us;
         }
         (void)hipMemsetAsync(L.x, 0, (size_t)L.n * 8, st_);

@@ -1935,8 +1935,10 @@ bool box2_plan(DevCsr &A)
     return A.box_q > 0;
 }
 
-// plan of the single-stage kernel: region = TY + 2 lines, one LDS plane, nothing recomputed; a workgroup's time ~ (CZ + 1) steps x Q points
-bool box1_plan(DevCsr &A)
+// plan of the single-stage kernel: region = TY + 2 lines, one LDS plane, nothing recomputed; a workgroup's time ~ (CZ + 1) steps x Q points.
+// shared_cu: count 512 slots for the instances of <= 3 points per thread (<= 64 VGPRs, <= 32 KB of LDS: two workgroups per CU, each at
+// ~1/1.6 speed) -- the alternative plan the setup times against the one-workgroup-per-CU plan (Engine::tune_box2)
+bool box1_plan(DevCsr &A, bool shared_cu)
 {
     A.box1_q = A.box1_ty = A.box1_cz = 0;
     const int nx = A.box_nx, ny = A.box_ny, nz = A.box_nz;
@@ -1950,8 +1952,10 @@ bool box1_plan(DevCsr &A)
         for (int zch = 1; zch <= nz; ++zch) {
             const int CZ = (nz + zch - 1) / zch;
             const int chunks = (nz + CZ - 1) / CZ;
-            const long wgs = (long)ytiles * chunks, rounds = (wgs + 255) / 256;
-            const long cost = rounds * (CZ + 1) * Q;
+            const long wgs = (long)ytiles * chunks;
+            long cost;
+            if (shared_cu && Q <= 3 && wgs > 256) cost = ((wgs + 511) / 512) * (CZ + 1) * Q * 16;
+            else cost = ((wgs + 255) / 256) * (CZ + 1) * Q * 10;
             if (best < 0 || cost < best) {
                 best = cost;
                 A.box1_q = Q;

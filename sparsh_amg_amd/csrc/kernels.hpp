@@ -207,7 +207,7 @@ void launch_box_resid_pair(const DevCsr &A, int axis, const double *x, const dou
 // y.b, 2 residual + pair restriction (aggregates = row pairs; y = coarse rhs, y2 = coarse zero-guess sweep, d / dconst = coarse diagonal),
 // 3 Jacobi sweep added to the finer iterate y2 (members / nfine as OP_JACOBI_PROLONG), 4 plain Jacobi sweep into y (the odd sweep of a leg
 // that runs double sweeps).  Returns the number of partial sums written.
-bool box1_plan(DevCsr &A);
+bool box1_plan(DevCsr &A, bool shared_cu = false);
 bool box1_applies(const DevCsr &A, const KernelConfig &cfg);
 int launch_box1(const DevCsr &A, int epi, const CsrArgs &a, bool finest, hipStream_t st);
 // OP_RESID_PAIR over the whole of A (a.y = coarse rhs, a.y2 = coarse iterate, a.d = coarse diagonal); applies to operators
