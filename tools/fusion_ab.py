@@ -26,18 +26,26 @@ def main():
     ap.add_argument("--iters", type=int, default=96)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--out", default=None)
-    ap.add_argument("--what", default="pair", choices=["pair", "prolong", "diag", "box2", "box1", "zero"])
+    ap.add_argument("--what", default="pair", choices=["pair", "prolong", "diag", "box2", "box1", "zero", "graph"])
     args = ap.parse_args()
     rp, ci, v = problems.poisson3d(args.n) if args.dim == 3 else problems.poisson2d(args.n)
     n = len(rp) - 1
     prm = sa.default_params(print_setup=0, print_solve=0, tol=0.0, check_every=1 << 30)
     A = sa.sp_matrix_mg(rp, ci, v).setup(prm)
+    if args.what == "graph":  # hipGraph replay of the iteration (sparsh_params.use_graph) against eager launches: two handles, same process
+        B = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(print_setup=0, print_solve=0, tol=0.0, check_every=1 << 30, use_graph=1))
+        handles = {True: B, False: A}
     if args.what == "pair":
         paired = [l for l in range(A.nlevels - 1) if A.level_paired(l)]
         toggle = A.set_paired_restriction
     elif args.what == "box2":
         paired = [(l, A.level_double_sweep(l)) for l in range(A.nlevels) if A.level_double_sweep(l)["grid"][0] > 0]
         toggle = lambda on: A.set_double_sweep(1 if on else 0)  # noqa: E731
+    elif args.what == "graph":
+        paired = []
+
+        def toggle(on):
+            cur[0] = handles[bool(on)]
     elif args.what == "zero":
         paired = [l for l in range(A.nlevels) if A.level_double_sweep(l)["on"]]
         toggle = A.set_zero_start
@@ -53,24 +61,26 @@ def main():
     print(f"# {args.dim}D n={args.n}: {n} rows, {A.nlevels} levels, {args.what}: fused levels {paired}", flush=True)
     bd, xd = A.dev_alloc(8 * n), A.dev_alloc(8 * n)
     A.h2d(bd, np.ones(n))
+    cur = [A]
 
     def run(iters):
+        H = cur[0]
         left = iters
         while left > 0:
-            A.dev_fill(xd, n, 0.0)
-            A.krylov_init_dev("pcg", bd, xd)
+            H.dev_fill(xd, n, 0.0)
+            H.krylov_init_dev("pcg", bd, xd)
             m = min(left, 48)
-            done, _ = A.krylov_step_dev(m)
+            done, _ = H.krylov_step_dev(m)
             assert done == m
             left -= m
-        A.sync()
+        H.sync()
 
     rates = {True: [], False: []}
     hist = {}
     for on in (True, False):
         toggle(on)
         run(48)
-        hist[on] = np.array(A.krylov_history())
+        hist[on] = np.array(cur[0].krylov_history())
     if args.what == "box1":  # the fused dot products are summed in another order: same histories to rounding
         k = min(30, len(hist[True]), len(hist[False]))
         assert np.allclose(hist[True][:k], hist[False][:k], rtol=1e-9), "histories differ beyond rounding"
