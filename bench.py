@@ -326,7 +326,9 @@ def main():
                 total += 4 * nl + 8 * ncl + 16 * nl
         total += coarse["bytes"] + 16 * levels[-1][0]
         n0, nnz0 = levels[0][0], levels[0][1]
-        total += layout_bytes(H, n0, nnz0, 0, 2) + ((48 if zero_written.get(0) is False else 56 + dvec[0])) * n0 + 24 * n0
+        # Krylov step: A p with the dot; residual update (Ap, r read; r [, z0] written [, d read]); x += alpha p and p = z + beta p in one kernel
+        # (z, p, x read; p, x written)
+        total += layout_bytes(H, n0, nnz0, 0, 2) + ((24 if zero_written.get(0) is False else 32 + dvec[0])) * n0 + 40 * n0
         return total
 
     def double_sweep(H):

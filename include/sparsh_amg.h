@@ -215,6 +215,10 @@ int sparsh_set_marching_ops(sparsh_handle h, int mode);
  * the iterate is not read at all (16 instead of 31 bytes per row for that launch).  Bitwise the three separate sweeps.
  * enable: 1 (default) / 0 (A/B). */
 int sparsh_set_zero_start(sparsh_handle h, int enable);
+/* PCG (Solver_PCG_*, src/AMG_main_solvers.cu): x += alpha p is applied by the kernel that updates the search direction at the end of
+ * the same iteration instead of by the one that updates the residual -- nothing reads x in between and p is then read once for both
+ * updates (one n-vector stream less per iteration).  Same expressions, same bits.  enable: 1 (default) / 0 (A/B). */
+int sparsh_set_deferred_x(sparsh_handle h, int enable);
 int sparsh_level_marching_ops(sparsh_handle h, int level, int *on, int *plan, double *table_us, double *marching_us);
 int sparsh_level_double_sweep(sparsh_handle h, int level, int *on, int *dims, int *plan, double *single_us, double *double_us);
 int sparsh_level_constant_diagonal(sparsh_handle h, int level, int *is_const, double *value);

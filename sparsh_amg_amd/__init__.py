@@ -97,6 +97,7 @@ def _load():
         "sparsh_set_double_sweep": (C.c_int, [H, C.c_int]),
         "sparsh_set_marching_ops": (C.c_int, [H, C.c_int]),
         "sparsh_set_zero_start": (C.c_int, [H, C.c_int]),
+        "sparsh_set_deferred_x": (C.c_int, [H, C.c_int]),
         "sparsh_level_marching_ops": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "sparsh_level_double_sweep": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                                   C.POINTER(C.c_double)]),
@@ -354,6 +355,11 @@ class sp_matrix_mg:
         _check(lib.sparsh_level_double_sweep(self._h, int(level), C.byref(on), dims, plan, C.byref(t1), C.byref(t2)))
         return {"on": bool(on.value), "grid": list(dims), "points_per_thread": plan[0], "lines_per_tile": plan[1], "planes_per_chunk": plan[2],
                 "two_single_sweeps_us": round(t1.value, 2), "double_sweep_us": round(t2.value, 2)}
+
+    def set_deferred_x(self, enable=True):
+        """PCG: x += alpha p rides in the direction update at the end of the iteration (p read once for both)."""
+        _check(lib.sparsh_set_deferred_x(self._h, 1 if enable else 0))
+        return self
 
     def set_zero_start(self, enable=True):
         """Double-sweep levels: a leg that starts from a zero guess runs sweeps 1 - 3 as one launch that reads only the right-hand side."""

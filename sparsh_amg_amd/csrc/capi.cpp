@@ -440,6 +440,14 @@ int sparsh_level_double_sweep(sparsh_handle h, int level, int *on, int *dims, in
     return SPARSH_OK;
 }
 
+int sparsh_set_deferred_x(sparsh_handle h, int enable)
+{
+    if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");
+    h->eng->kernel_cfg().defer_x = enable != 0;
+    h->eng->config_changed();
+    return SPARSH_OK;
+}
+
 int sparsh_set_zero_start(sparsh_handle h, int enable)
 {
     if (!h || !h->eng) return fail(SPARSH_EINVAL, "null handle");

@@ -2033,10 +2033,13 @@ void Engine::pcg_body(bool precond, int slot)
     // (... unless the cycle's first launch on level 0 is the three-sweep one, which reads r alone)
     const bool fuse_zero = cfg_.fuse_cg_zero && precond && !f32_ready_ && lev_.size() > 1 && !lev_[0].deep && prm_.sweeps > 0 &&
                            !(prm_.sweeps >= 3 && zero_start(lev_[0]));
+    // with the fp64 V-cycle behind it x += alpha p waits for the direction update at the end of this iteration (one read of p for both)
+    const bool defer_x = cfg_.defer_x && precond && !f32_ready_;
+    double *x_now = defer_x ? nullptr : x;
     if (fuse_zero)
-        launch_cg_update_zero(n, scal_, p, Ap, x, r, part1_, &nb, diag_stream(lev_[0]), lev_[0].diag_const, prm_.omega, lev_[0].x, st_, cfg_.cg_nt);
+        launch_cg_update_zero(n, scal_, p, Ap, x_now, r, part1_, &nb, diag_stream(lev_[0]), lev_[0].diag_const, prm_.omega, lev_[0].x, st_, cfg_.cg_nt);
     else
-        launch_cg_update(n, scal_, p, Ap, x, r, precond ? part1_ : part0_, &nb, st_);
+        launch_cg_update(n, scal_, p, Ap, x_now, r, precond ? part1_ : part0_, &nb, st_);
     if (precond && f32_ready_) {
         const int nb_rr = nb;
         vcycle_f32(r, work_[4], part0_, &nb);  // float hierarchy, fp64 in/out, fused z0.r0
@@ -2046,7 +2049,8 @@ void Engine::pcg_body(bool precond, int slot)
         const int nb_rr = nb;
         vcycle(r, true, part0_, &nb, fuse_zero);  // z0 = 0 ; z0 = V(r0) ; fused z0.r0
         finalize(FIN_PCG_BETA_RES, part0_, part1_, nb, 0, hist_dev_, slot, nb_rr);
-        launch_p_update(n, scal_, lev_[0].x, p, st_);  // p = z0 + beta p
+        if (defer_x) launch_xp_update(n, scal_, lev_[0].x, p, x, st_);  // x += alpha p ; p = z0 + beta p
+        else launch_p_update(n, scal_, lev_[0].x, p, st_);                // p = z0 + beta p
     } else {
         finalize(FIN_CG_BETA, part0_, nullptr, nb, 0, hist_dev_, slot);
         launch_p_update(n, scal_, r, p, st_);

@@ -2335,7 +2335,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int n, const double *
     const double alpha = scal[S_ALPHA], nalpha = scal[S_NALPHA];
     double acc = 0.0;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        x[i] = x[i] + alpha * p[i];        // cblas_daxpy(alpha, p, x)
+        if (x) x[i] = x[i] + alpha * p[i];        // cblas_daxpy(alpha, p, x)   (x == nullptr: left to xp_update_kernel)
         const double ri = r[i] + nalpha * Ap[i];  // cblas_daxpy(-alpha, Ap, r)
         r[i] = ri;
         acc += ri * ri;
@@ -2359,13 +2359,15 @@ __global__ __launch_bounds__(kBlock) void cg_update_zero_kernel(int n, const dou
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         // NT: x, p, Ap and d are not touched again before the cycle is over -- streamed past the caches, so that r and z0, which the
         // first sweep of the cycle reads next, are what stays resident
-        const double xi = NT ? __builtin_nontemporal_load(x + i) : x[i];
-        const double pi = NT ? __builtin_nontemporal_load(p + i) : p[i];
         const double api = NT ? __builtin_nontemporal_load(Ap + i) : Ap[i];
         const double di = !d ? dconst : (NT ? __builtin_nontemporal_load(d + i) : d[i]);
-        const double xn = xi + alpha * pi;
-        if (NT) __builtin_nontemporal_store(xn, x + i);
-        else x[i] = xn;
+        if (x) {  // (x == nullptr: left to xp_update_kernel)
+            const double xi = NT ? __builtin_nontemporal_load(x + i) : x[i];
+            const double pi = NT ? __builtin_nontemporal_load(p + i) : p[i];
+            const double xn = xi + alpha * pi;
+            if (NT) __builtin_nontemporal_store(xn, x + i);
+            else x[i] = xn;
+        }
         const double ri = r[i] + nalpha * api;
         r[i] = ri;
         z0[i] = omega * ri / di;
@@ -2380,6 +2382,21 @@ __global__ __launch_bounds__(kBlock) void p_update_kernel(int n, const double *_
 {
     const double beta = scal[S_BETA];
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) p[i] = 1.0 * z[i] + beta * p[i];
+}
+
+// PCG: x += alpha p moved from the residual update to the direction update at the end of the same iteration -- nothing reads x in
+// between, alpha is still in its slot, and p is read once for both: x_i + alpha p_i and 1.0 z_i + beta p_i as before (one n-vector
+// stream less per iteration)
+__global__ __launch_bounds__(kBlock) void xp_update_kernel(int n, const double *__restrict__ scal, const double *__restrict__ z,
+                                                            double *__restrict__ p, double *__restrict__ x)
+{
+    const double alpha = scal[S_ALPHA], beta = scal[S_BETA];
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const double pi = p[i];
+        const double xi = __builtin_nontemporal_load(x + i);
+        __builtin_nontemporal_store(xi + alpha * pi, x + i);
+        p[i] = 1.0 * z[i] + beta * pi;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void bicg_s_kernel(int n, const double *__restrict__ scal, const double *__restrict__ r,
@@ -2811,6 +2828,11 @@ void launch_cg_update_zero(int n, const double *scal, const double *p, const dou
         hipLaunchKernelGGL(cg_update_zero_kernel<true>, dim3(g), dim3(kBlock), 0, st, n, scal, p, Ap, x, r, partial, d, dconst, omega, z0);
     else
         hipLaunchKernelGGL(cg_update_zero_kernel<false>, dim3(g), dim3(kBlock), 0, st, n, scal, p, Ap, x, r, partial, d, dconst, omega, z0);
+}
+
+void launch_xp_update(int n, const double *scal, const double *z, double *p, double *x, hipStream_t st)
+{
+    hipLaunchKernelGGL(xp_update_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, st, n, scal, z, p, x);
 }
 
 void launch_p_update(int n, const double *scal, const double *z, double *p, hipStream_t st)

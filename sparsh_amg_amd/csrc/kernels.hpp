@@ -110,6 +110,8 @@ struct KernelConfig {
     bool fuse_cg_zero = true; // PCG: the cg_update kernel also writes the V-cycle's zero-guess sweep of level 0
     int alt_dir = 1;          // consecutive sweeps of a smoothing leg walk the level in alternating directions (CsrArgs::reverse):
                               // 0 never, 1 where a sweep streams more than 640 MB (2.5x the Infinity Cache), 2 always
+    bool defer_x = true;       // PCG: x += alpha p rides in the direction update at the end of the iteration (xp_update_kernel) instead of in the
+                               // residual update: p is read once for both
     bool zero_start = true;    // double-sweep levels: a leg that starts from a zero guess runs its first three sweeps as one launch that
                                // reads only the right-hand side (launch_box2 from_zero)
     int box1 = 1;              // box-grid levels: the launches with an epilogue of their own (SpMV + dot, last post-sweep + dot / + prolongation,
@@ -307,6 +309,8 @@ void launch_cg_update_zero(int n, const double *scal, const double *p, const dou
                            int *nblk, const double *d, double dconst, double omega, double *z0, hipStream_t st, bool nt = false);
 // p = 1.0*z + beta*p
 void launch_p_update(int n, const double *scal, const double *z, double *p, hipStream_t st);
+// x += alpha p ; p = 1.0*z + beta*p  (PCG with the x update moved here: launch_cg_update / _zero are then called with x = nullptr)
+void launch_xp_update(int n, const double *scal, const double *z, double *p, double *x, hipStream_t st);
 // two dots at once: partial0 += a.b, partial1 += c.d
 void launch_dot2(int n, const double *a, const double *b, const double *c, const double *d, double *partial0, double *partial1,
                  int *nblk, hipStream_t st);

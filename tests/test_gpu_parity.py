@@ -991,3 +991,34 @@ def test_box_kernels_with_a_different_constant_per_offset(dims, coef):
     xo, ho = H.solve(b, iterations=3)
     assert np.allclose(ha, ho, rtol=1e-10) and np.linalg.norm(xa - xo) <= 1e-10 * np.linalg.norm(xo)
     A.close()
+
+
+@pytest.mark.parametrize("name,gen", [
+    ("p3d_30", lambda: problems.poisson3d(30)),
+    ("ragged", lambda: problems.random_spd(20000, 9, seed=11)),
+])
+def test_deferred_x_update_bitwise(name, gen):
+    """PCG: x += alpha p applied by the direction update at the end of the iteration (xp_update_kernel) instead of by the residual
+    update: same histories and solutions bit for bit, through solve() and through the stepwise session."""
+    rp, ci, v = gen()
+    n = len(rp) - 1
+    b = np.random.default_rng(89).standard_normal(n)
+    A = sa.sp_matrix_mg(rp, ci, v).setup(sa.default_params(**QUIET))
+    out = {}
+    for on in (True, False):
+        A.set_deferred_x(on)
+        x = np.zeros(n)
+        h, rc = A.solve("pcg", b, x)
+        assert rc == 0
+        bd, xd = A.dev_alloc(8 * n), A.dev_alloc(8 * n)
+        A.h2d(bd, b)
+        A.h2d(xd, np.zeros(n))
+        A.krylov_init_dev("pcg", bd, xd)
+        A.krylov_step_dev(3)
+        A.krylov_step_dev(2)
+        xs = np.zeros(n)
+        A.d2h(xs, xd)
+        out[on] = (np.array(h), x, np.array(A.krylov_history()), xs)
+    for k in range(4):
+        assert np.array_equal(out[True][k], out[False][k]), (name, k)
+    A.close()

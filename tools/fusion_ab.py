@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--iters", type=int, default=96)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--out", default=None)
-    ap.add_argument("--what", default="pair", choices=["pair", "prolong", "diag", "box2", "box1", "zero", "graph"])
+    ap.add_argument("--what", default="pair", choices=["pair", "prolong", "diag", "box2", "box1", "zero", "graph", "deferx"])
     args = ap.parse_args()
     rp, ci, v = problems.poisson3d(args.n) if args.dim == 3 else problems.poisson2d(args.n)
     n = len(rp) - 1
@@ -46,6 +46,9 @@ def main():
 
         def toggle(on):
             cur[0] = handles[bool(on)]
+    elif args.what == "deferx":
+        paired = []
+        toggle = A.set_deferred_x
     elif args.what == "zero":
         paired = [l for l in range(A.nlevels) if A.level_double_sweep(l)["on"]]
         toggle = A.set_zero_start
