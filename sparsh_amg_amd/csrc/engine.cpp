@@ -640,7 +640,7 @@ int Engine::setup_host_shared(const sparsh_params &p)
 // Box-grid levels: does the double sweep (sdia_box2_kernel) beat two single sweeps here?  Timed on the level's own buffers
 // (KernelConfig::box2 = 1, levels of >= 400 000 rows: below that two launches of a cache-resident level win, tools/micro/box2_proto)
 // or switched on wherever a plan exists (box2 = 2: tests, A/B).
-void Engine::tune_box2()
+void Engine::tune_box_kernels()
 {
     for (size_t l = 0; l + 1 < lev_.size(); ++l) {
         DevLevel &L = lev_[l];
@@ -1408,7 +1408,7 @@ int Engine::setup(const sparsh_params &p)
     place_tried = 0;
     place_best_us = place_worst_us = place_first_us = 0.0;
     phase("coarsest-level factorisation + workspace");
-    tune_box2();
+    tune_box_kernels();
     if (G == 1 && cfg_.place_search) tune_placement();
     phase("placement search");
     f32_ready_ = false;

@@ -41,7 +41,7 @@ struct DevLevel {
     bool pair_aggregates = false;  // aggregate J = fine rows (2J, 2J+1) in R's stored order: residual + restriction fuse (OP_RESID_PAIR)
     double *diag = nullptr;
     double box1_table_us = 0.0, box1_us = 0.0;        // setup timing of the last post-sweep + dot: table kernel / plane-marching kernel
-    double box_single_us = 0.0, box_double_us = 0.0;  // setup timing of two single sweeps / one double sweep (tune_box2), 0 = not timed
+    double box_single_us = 0.0, box_double_us = 0.0;  // setup timing of two single sweeps / one double sweep (tune_box_kernels), 0 = not timed
     bool diag_is_const = false;  // every (own) row has the same diagonal entry, diag_const
     double diag_const = 0.0;
     double *x = nullptr, *x2 = nullptr;  // ping-pong solution buffers (Jacobi reads old, writes new)
@@ -319,7 +319,7 @@ private:
     std::vector<void *> allocs_;
     // which of the finest level's equally sized buffers play iterate / ping-pong twin / Krylov residual: chosen at setup by
     // timing the sweep on the candidates (see tune_placement)
-    void tune_box2();
+    void tune_box_kernels();
     void tune_placement();
 };
 

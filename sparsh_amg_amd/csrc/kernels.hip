@@ -1937,7 +1937,7 @@ bool box2_plan(DevCsr &A)
 
 // plan of the single-stage kernel: region = TY + 2 lines, one LDS plane, nothing recomputed; a workgroup's time ~ (CZ + 1) steps x Q points.
 // shared_cu: count 512 slots for the instances of <= 3 points per thread (<= 64 VGPRs, <= 32 KB of LDS: two workgroups per CU, each at
-// ~1/1.6 speed) -- the alternative plan the setup times against the one-workgroup-per-CU plan (Engine::tune_box2)
+// ~1/1.6 speed) -- the alternative plan the setup times against the one-workgroup-per-CU plan (Engine::tune_box_kernels)
 bool box1_plan(DevCsr &A, bool shared_cu)
 {
     A.box1_q = A.box1_ty = A.box1_cz = 0;
