@@ -393,6 +393,9 @@ def main():
             single = layout_bytes(A, pr["nrow"], pr["nnz"])
             roof["sweeps_per_launch"] = 2
             roof["us_per_sweep"] = round(avg * 1e6 / 2, 2)
+            # what two launches of the single-sweep kernel would have to sustain to finish in the same time: an EFFECTIVE rate (above the HBM
+            # peak: the point of temporal blocking), not a bandwidth
+            roof["two_single_sweeps_equivalent_GBps"] = round(2 * single / avg / 1e9, 1)
             roof["double_sweep"] = A.level_double_sweep(0)
             roof["note"] = ("the dominant kernel is the double sweep (sparsh_set_double_sweep; DESIGN.md section 4): ONE launch performs TWO Jacobi sweeps of the finest level in one "
                             "pass over x, b and the result (temporal blocking: the first sweep's plane stays in LDS, its halo is recomputed). achieved/frac price a LAUNCH with the "
