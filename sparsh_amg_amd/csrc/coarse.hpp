@@ -72,6 +72,8 @@ public:
     bool setup_nd(const HostCsr &A, hipStream_t st, std::string &err, int *why_failed = nullptr);
     // x = A^-1 b, device vectors in the operator's own numbering; enqueues on st
     void solve(const double *b, double *x, hipStream_t st) const;
+    // nested-dissection form only: the solve's backward pass also prolongates into the finer level (NdProlong)
+    void solve_prolong(const double *b, double *x, hipStream_t st, NdProlong pr) const { nd_.solve(b, x, st, pr); }
     void release();
 
     bool ready() const { return n_ > 0; }

@@ -1921,10 +1921,25 @@ void Engine::vcycle(const double *b0, bool x0_zero, double *dot_partial, int *do
         op_residual(l, L.b, L.x, L.r);                                      // store_residual
         zero_done = op_restrict(l, L.r, lev_[l + 1].b, nu > 0 && !next_from_b);  // transfer_residual (+ x_{l+1} = omega*b/d)
     }
-    op_coarse(lev_[last].b, lev_[last].x);  // Direct_Solver_Pardiso_solve
+    bool coarse_prolonged = false;
+    {
+        DevLevel &F = lev_[last - 1];
+        if (coarse_.nested() && cfg_.fuse_prolong && (!dist_ || F.replicated) && !F.deep && F.P_is_aggregation && (F.pair_aggregates || F.members) &&
+            F.R.nrow == lev_[last].n && !prm_.precond_fp32) {
+            // Direct_Solver_Pardiso_solve + transfer_solution: the backward pass of the nested-dissection solve adds x_L to the rows it owns
+            NdProlong pr;
+            pr.xf = F.x;
+            pr.members = F.pair_aggregates ? nullptr : F.members;
+            pr.nfine = F.n;
+            coarse_.solve_prolong(lev_[last].b, lev_[last].x, st_, pr);
+            coarse_prolonged = true;
+        } else {
+            op_coarse(lev_[last].b, lev_[last].x);  // Direct_Solver_Pardiso_solve
+        }
+    }
     for (int l = last; l > 0; --l) {
         DevLevel &F = lev_[l - 1];
-        if (!level_prolong_fused(l)) op_prolong(l - 1, lev_[l].x, F.x);  // transfer_solution (else: done by level l's last post-sweep)
+        if (!(l == last ? coarse_prolonged : level_prolong_fused(l))) op_prolong(l - 1, lev_[l].x, F.x);  // transfer_solution (else: done by the launch before)
         if (F.deep) deep_exchange(F, 2, F.x);  // the leg's only exchange: K ghost layers of the prolongated iterate
         const bool want_dot = (l - 1 == 0) && dot_partial;
         smooth(F, F.b, nu, false, want_dot ? dot_partial : nullptr, dot_nblk, false, level_prolong_fused(l - 1) ? &lev_[l - 2] : nullptr);

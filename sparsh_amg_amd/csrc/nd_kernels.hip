@@ -352,7 +352,7 @@ __global__ __launch_bounds__(kNB) void nd_repack_kernel(long long nseg, const Nd
 template <bool FWD>
 __global__ __launch_bounds__(kNB) void nd_gdot_kernel(const NdRow *__restrict__ rows, int nrows, int nwide, int n, const double *__restrict__ M,
                                                       const int *__restrict__ idx, double *__restrict__ w, const double *__restrict__ b,
-                                                      double *__restrict__ x)
+                                                      double *__restrict__ x, NdProlong pr)
 {
     __shared__ double part[kNB / 64];
     const int lane = threadIdx.x & 63;
@@ -401,6 +401,16 @@ __global__ __launch_bounds__(kNB) void nd_gdot_kernel(const NdRow *__restrict__ 
     } else {
         w[n + R.out] = a;
         x[R.bsrc] = a;
+        if (pr.xf) {  // the finer level's rows this coarse row owns: x_f = 1.0 * x_c + x_f
+            const int J = R.bsrc;
+            int f0 = 2 * J, f1 = 2 * J + 1 < pr.nfine ? 2 * J + 1 : -1;
+            if (pr.members) {
+                f0 = pr.members[2 * (size_t)J];
+                f1 = pr.members[2 * (size_t)J + 1];
+            }
+            pr.xf[f0] = 1.0 * a + pr.xf[f0];
+            if (f1 >= 0) pr.xf[f1] = 1.0 * a + pr.xf[f1];
+        }
     }
 }
 
@@ -450,14 +460,14 @@ void nd_launch_repack(long long nseg, const NdSegment *segs, const double *Lh, d
 }
 
 void nd_launch_pass(bool forward, const NdRow *rows, int nrows, int nwide, int n, const double *M, const int *idx, double *w, const double *b, double *x,
-                    hipStream_t st)
+                    hipStream_t st, NdProlong pr)
 {
     if (nrows <= 0) return;
     const int grid = nwide + (nrows - nwide + kNB / 64 - 1) / (kNB / 64);
     if (forward)
-        hipLaunchKernelGGL(nd_gdot_kernel<true>, dim3(grid), dim3(kNB), 0, st, rows, nrows, nwide, n, M, idx, w, b, x);
+        hipLaunchKernelGGL(nd_gdot_kernel<true>, dim3(grid), dim3(kNB), 0, st, rows, nrows, nwide, n, M, idx, w, b, x, NdProlong());
     else
-        hipLaunchKernelGGL(nd_gdot_kernel<false>, dim3(grid), dim3(kNB), 0, st, rows, nrows, nwide, n, M, idx, w, b, x);
+        hipLaunchKernelGGL(nd_gdot_kernel<false>, dim3(grid), dim3(kNB), 0, st, rows, nrows, nwide, n, M, idx, w, b, x, pr);
 }
 
 }  // namespace sparsh

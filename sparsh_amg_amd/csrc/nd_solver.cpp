@@ -294,11 +294,11 @@ bool NdSolver::setup(const HostCsr &A, const NdParams &prm, hipStream_t st, std:
     return true;
 }
 
-void NdSolver::solve(const double *b, double *x, hipStream_t st) const
+void NdSolver::solve(const double *b, double *x, hipStream_t st, NdProlong pr) const
 {
     if (n_ <= 0) return;
     for (int l = 1; l < nlevels_; ++l) nd_launch_pass(true, fwd_[l].rows, fwd_[l].nrows, fwd_[l].nwide, n_, Lf_, fidx_, w_, b, x, st);
-    for (int l = nlevels_ - 1; l >= 0; --l) nd_launch_pass(false, bwd_[l].rows, bwd_[l].nrows, bwd_[l].nwide, n_, Bm_, bidx_, w_, b, x, st);
+    for (int l = nlevels_ - 1; l >= 0; --l) nd_launch_pass(false, bwd_[l].rows, bwd_[l].nrows, bwd_[l].nwide, n_, Bm_, bidx_, w_, b, x, st, pr);
 }
 
 }  // namespace sparsh

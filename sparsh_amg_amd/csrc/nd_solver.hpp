@@ -34,6 +34,14 @@ struct NdGjNode {  // one pivot block of the batched whole-chip inversion (nd_ke
     int p, lda, ldb, ldo, wg0;  // wg0: first workgroup of this node in the launch
 };
 
+// transfer_solution fused into the backward pass (aggregation prolongator: every fine row has one owner): x_f = 1.0 * x_c + x_f for the (at most
+// two) fine rows of coarse row J -- members[2J], members[2J + 1] (-1: none), or rows 2J, 2J + 1 when members is null
+struct NdProlong {
+    double *xf = nullptr;
+    const int *members = nullptr;
+    int nfine = 0;
+};
+
 class NdSolver {
 public:
     ~NdSolver() { release(); }
@@ -45,7 +53,8 @@ public:
     bool plan(const HostCsr &A, const NdParams &prm, std::string &err);
     // why_failed: 1 the plan was refused (graph / memory limits), 2 singular, 3 device error
     bool setup(const HostCsr &A, const NdParams &prm, hipStream_t st, std::string &err, int *why_failed);
-    void solve(const double *b, double *x, hipStream_t st) const;  // device vectors, the operator's own numbering
+    // device vectors, the operator's own numbering; pr: the backward pass also adds every x it produces to the rows of the finer level that row owns
+    void solve(const double *b, double *x, hipStream_t st, NdProlong pr = NdProlong()) const;
     void release();
 
     bool ready() const { return n_ > 0; }
@@ -81,7 +90,7 @@ void nd_launch_gj_batched(const NdGjNode *nodes, int nnodes, const int *wg_node,
 void nd_launch_gemm(const NdGemm *problems, const int *tiles, int ntiles, hipStream_t st);
 void nd_launch_repack(long long nseg, const NdSegment *segs, const double *Lh, double *Lf, hipStream_t st);
 void nd_launch_pass(bool forward, const NdRow *rows, int nrows, int nwide, int n, const double *M, const int *idx, double *w, const double *b, double *x,
-                    hipStream_t st);
+                    hipStream_t st, NdProlong pr = NdProlong());
 constexpr int kNdTinyPivot = 80;     // pivot blocks up to this many rows are inverted by one workgroup in LDS (80 x 81 doubles = 51 KB);
                                      // larger ones by the batched whole-chip inversion
 
